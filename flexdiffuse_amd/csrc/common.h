@@ -1,0 +1,60 @@
+// Shared host-side helpers for libflexdiffuse_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/flexdiffuse_hip.h"
+
+void fd_set_error(const char* fmt, ...);
+
+#define FD_CHECK_ARG(cond, code, ...)                  \
+    do {                                               \
+        if (!(cond)) {                                 \
+            fd_set_error(__VA_ARGS__);                 \
+            return (code);                             \
+        }                                              \
+    } while (0)
+
+#define FD_CHECK_LAUNCH(name)                                                    \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            fd_set_error("%s: launch failed: %s", (name), hipGetErrorString(e_)); \
+            return FD_EHIP;                                                      \
+        }                                                                        \
+    } while (0)
+
+#define FD_HIP(call)                                                                 \
+    do {                                                                             \
+        hipError_t e_ = (call);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            fd_set_error("%s failed: %s", #call, hipGetErrorString(e_));             \
+            return FD_EHIP;                                                          \
+        }                                                                            \
+    } while (0)
+
+static inline int fd_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// optional per-launch HIP-event timing of a kernel family (bench.py roofline leg)
+void fd_prof_begin(int family, hipStream_t s, double work);
+void fd_prof_end(int family, hipStream_t s);
+
+typedef _Float16 half_t;
+typedef half_t half8 __attribute__((ext_vector_type(8)));
+typedef half_t half4 __attribute__((ext_vector_type(4)));
+typedef half_t half2v __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float fd_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float fd_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,111 @@
+// Library-level plumbing: thread-local error string, device query, and the optional
+// per-launch HIP-event recorder used by bench.py's roofline leg (events are recorded
+// on the stream each kernel is launched on).
+#include <stdarg.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void fd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* fd_last_error(void) { return g_err; }
+extern "C" int fd_abi_version(void) { return FD_ABI_VERSION; }
+
+extern "C" int fd_device_info(int device, int* cu_count, int* clock_khz, int64_t* hbm_bytes,
+                              char* arch, int arch_len) {
+    hipDeviceProp_t prop;
+    FD_HIP(hipGetDeviceProperties(&prop, device));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (arch && arch_len > 0) {
+        strncpy(arch, prop.gcnArchName, arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    return FD_OK;
+}
+
+// ---- kernel-family timing recorder -------------------------------------------------
+struct ProfRec {
+    int family;
+    double work;
+    hipEvent_t e0, e1;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_pool;
+
+static hipEvent_t prof_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+void fd_prof_begin(int family, hipStream_t s, double work) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    r.family = family;
+    r.work = work;
+    r.e0 = prof_event();
+    r.e1 = prof_event();
+    hipEventRecord(r.e0, s);
+    g_prof.push_back(r);
+}
+
+void fd_prof_end(int family, hipStream_t s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof.empty() && g_prof.back().family == family) hipEventRecord(g_prof.back().e1, s);
+}
+
+extern "C" int fd_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return FD_OK;
+}
+
+// Sums (after synchronising the recorded events) the elapsed ms, the declared work
+// (FLOPs or bytes) and the launch count of `family`; then forgets those records.
+extern "C" int fd_prof_collect(int family, double* total_ms, double* total_work,
+                               int64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double ms = 0, work = 0;
+    int64_t n = 0;
+    std::vector<ProfRec> keep;
+    for (auto& r : g_prof) {
+        if (r.family != family) {
+            keep.push_back(r);
+            continue;
+        }
+        float t = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess &&
+            hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+            ms += t;
+            work += r.work;
+            ++n;
+        }
+        g_pool.push_back(r.e0);
+        g_pool.push_back(r.e1);
+    }
+    g_prof.swap(keep);
+    if (total_ms) *total_ms = ms;
+    if (total_work) *total_work = work;
+    if (launches) *launches = n;
+    return FD_OK;
+}

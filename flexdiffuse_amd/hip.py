@@ -1,0 +1,119 @@
+'''ctypes binding of libflexdiffuse_hip.so (include/flexdiffuse_hip.h).
+
+There is NO fallback: if the shared object is missing or a tensor is not on a HIP
+device, calls raise.  PyTorch is used only for device memory and streams.
+'''
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libflexdiffuse_hip.so')
+
+FD_OK, FD_EINVAL, FD_ESHAPE, FD_EHIP = 0, -1, -2, -3
+
+
+class FDError(RuntimeError):
+    '''HIP runtime failure reported by libflexdiffuse_hip.so (FD_EHIP).'''
+
+
+class fd_tween_params(ctypes.Structure):
+    _fields_ = [('threshold_floor', c_double), ('threshold_mult', c_double),
+                ('clustered', c_double), ('max_guidance', c_double),
+                ('header_max', c_double), ('order', c_int32), ('reuse', c_int32)]
+
+
+P = c_void_p
+_SIGNATURES = {
+    'fd_abi_version': (c_int, []),
+    'fd_last_error': (c_char_p, []),
+    'fd_device_info': (c_int, [c_int, P, P, P, P, c_int]),
+    'fd_prof_enable': (c_int, [c_int]),
+    'fd_prof_collect': (c_int, [c_int, P, P, P]),
+    'fd_guidance_workspace_floats': (c_int64, [c_int, c_int, c_int]),
+    'fd_guidance_map': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'fd_guidance_tween': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int,
+                                  ctypes.POINTER(fd_tween_params), P]),
+    'fd_guidance_concept_override': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    'fd_guidance_header_pull': (c_int, [P, P, c_int, c_int, c_int, P]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib() -> ctypes.CDLL:
+    '''Load (once) and return the shared object; raises if it has not been built.'''
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: the HIP extension has not been built. Run '
+                '`python -c "import __graft_entry__ as g; g.build()"` (or `make -C '
+                'flexdiffuse_amd/csrc`). flexdiffuse_amd has no CPU fallback.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        if handle.fd_abi_version() != 1:
+            raise RuntimeError('libflexdiffuse_hip.so ABI version mismatch; rebuild')
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ''):
+    if rc == FD_OK:
+        return
+    msg = lib().fd_last_error().decode('utf-8', 'replace')
+    if rc in (FD_EINVAL, FD_ESHAPE):
+        raise ValueError(f'{what}: {msg}')
+    raise FDError(f'{what}: {msg} (code {rc})')
+
+
+def call(name: str, *args):
+    check(getattr(lib(), name)(*args), name)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('flexdiffuse_amd runs on an MI355X HIP device only; got a '
+                               f'{t.device} tensor (there is no CPU fallback)')
+
+
+def ptr(t: Optional[torch.Tensor]) -> c_void_p:
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device_info(device: int = 0) -> dict:
+    cu, khz, mem = c_int(0), c_int(0), c_int64(0)
+    arch = ctypes.create_string_buffer(64)
+    call('fd_device_info', device, ctypes.byref(cu), ctypes.byref(khz), ctypes.byref(mem),
+         arch, 64)
+    return {'cu_count': cu.value, 'clock_khz': khz.value, 'hbm_bytes': mem.value,
+            'arch': arch.value.decode()}
+
+
+def prof_enable(on: bool):
+    call('fd_prof_enable', int(bool(on)))
+
+
+def prof_collect(family: int):
+    ms, work, n = c_double(0), c_double(0), c_int64(0)
+    call('fd_prof_collect', family, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
+    return ms.value, work.value, n.value

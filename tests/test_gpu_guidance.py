@@ -1,0 +1,130 @@
+'''Parity of the HIP guidance kernels (through the C ABI) with the oracle and with the
+golden vectors captured from the reference.  Needs an MI355X.'''
+import hashlib
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import BIG_SCENES, SMALL_SCENES, load_scene
+
+pytestmark = pytest.mark.gpu
+
+S_TOL = 1e-5      # |delta s| bar; indices must be equal
+W_TOL = 1e-6      # weights / outputs vs goldens
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('name', SMALL_SCENES + BIG_SCENES)
+def test_map_emb_vs_reference_goldens(guidance_goldens, dev, name):
+    from flexdiffuse_amd import guidance as FG
+    g = guidance_goldens
+    alt, txt = load_scene(g, name)
+    ta, tt = torch.from_numpy(alt).to(dev), torch.from_numpy(txt).to(dev)
+    for mode, reuse in itertools.product((0, 1, 2), (True, False)):
+        want = g[f'{name}/map_m{mode}_r{int(reuse)}']
+        got = FG._map_emb(ta, tt, reuse, mode)
+        assert got.shape == want.shape and got.dtype == np.float64
+        assert np.array_equal(got[:, 0], want[:, 0]), (name, mode, reuse)
+        assert np.max(np.abs(got[:, 1] - want[:, 1])) <= S_TOL, (name, mode, reuse)
+
+
+@pytest.mark.parametrize('name', SMALL_SCENES + BIG_SCENES)
+def test_tween_vs_reference_goldens(guidance_goldens, dev, name):
+    from flexdiffuse_amd import guidance as FG
+    from oracle import guidance_ref as G
+    g = guidance_goldens
+    alt, txt = load_scene(g, name)
+    ta, tt = torch.from_numpy(alt).to(dev), torch.from_numpy(txt).to(dev)
+    names = [str(n) for n in g['tween_sets/names']]
+    for tname, vals in zip(names, g['tween_sets/values']):
+        fl, mu, l0, l1, cl, mg, hm, mode, reuse = (float(v) for v in vals)
+        key = f'{name}/tween_{tname}'
+        tw = FG.Tweener((fl, mu), (l0, l1), cl, mg, hm, int(mode), bool(reuse))
+        if key + '/zerodiv' in g.files:
+            with pytest.raises(ZeroDivisionError):
+                tw.tween(tt, ta)
+            continue
+        out = tw.tween(tt, ta).cpu().numpy()
+        w = tw.last_weights[0].cpu().numpy()
+        assert np.max(np.abs(w - g[key + '/weights'])) <= W_TOL, key
+        # oracle on the same inputs, fed the device's own mapping: bit-exact blend
+        idx, s = tw.last_map
+        mapped = np.zeros((77, 2))
+        mapped[:, 0] = idx[0].cpu().numpy()
+        mapped[:, 1] = s[0].cpu().numpy().astype(np.float64)
+        o_out, o_w, _ = G.tween(txt, alt, threshold=(fl, mu), linear=(l0, l1), clustered=cl,
+                                max_guidance=mg, header_max=hm, order=int(mode),
+                                reuse=bool(reuse), mapped=mapped)
+        assert np.array_equal(o_w.numpy(), w), key + ' weights not bit-exact vs oracle'
+        assert np.array_equal(o_out.numpy(), out), key + ' blend not bit-exact vs oracle'
+        if key + '/out' in g.files:
+            assert np.max(np.abs(out - g[key + '/out'])) <= W_TOL, key
+        else:
+            assert np.max(np.abs(out[0, :, :8] - g[key + '/out_head'])) <= W_TOL, key
+
+
+def test_batched_prompts_equal_single(guidance_goldens, dev):
+    '''B prompts against one guide in one launch == B single-prompt calls.'''
+    from flexdiffuse_amd import guidance as FG
+    g = guidance_goldens
+    alt, _ = load_scene(g, 'b0_257x768')
+    rng = np.random.default_rng(7)
+    txt = rng.standard_normal((8, 77, 768)).astype(np.float32)
+    txt[3, 5] = alt[0, 100] * 1.5
+    ta, tt = torch.from_numpy(alt).to(dev), torch.from_numpy(txt).to(dev)
+    tw = FG.Tweener((0.75, 0.25), (0.0, 0.5), 0.0, 0.35, 0.0, 1, True)
+    batched = tw.tween(tt, ta)
+    for b in range(8):
+        single = tw.tween(tt[b:b + 1], ta)
+        assert torch.equal(single[0], batched[b])
+    idx, s = tw.last_map
+    assert batched.shape == (8, 77, 768)
+
+
+def test_underflow_edge_cases(dev):
+    '''Columns whose similarity underflows to exactly 0 never lock (guidance.py:80).'''
+    from flexdiffuse_amd import guidance as FG
+    from oracle import guidance_ref as G
+    rng = np.random.default_rng(11)
+    D = 64
+    alt = rng.standard_normal((1, 40, D)).astype(np.float32)
+    txt = rng.standard_normal((1, 77, D)).astype(np.float32)
+    # every guide token is (nearly) text token 3 -> all other columns underflow to 0
+    for i in range(40):
+        alt[0, i] = txt[0, 3] * (1.0 + 0.01 * i) + 1e-3 * rng.standard_normal(D).astype(np.float32)
+    ta, tt = torch.from_numpy(alt).to(dev), torch.from_numpy(txt).to(dev)
+    sim = G.similarity(alt, txt)
+    assert (sim[:, 10] == 0).all(), 'test construction: expected underflow'
+    for mode, reuse in itertools.product((0, 1, 2), (True, False)):
+        want = G.assign(sim, 77, reuse, mode)
+        got = FG._map_emb(ta, tt, reuse, mode)
+        assert np.array_equal(got[:, 0], want[:, 0]), (mode, reuse, got[:8], want[:8])
+        assert np.max(np.abs(got[:, 1] - want[:, 1])) <= S_TOL
+
+
+@pytest.mark.parametrize('k', [0, 1, 2])
+def test_concept_mapper(guidance_goldens, dev, k):
+    from flexdiffuse_amd import guidance as FG
+    g = guidance_goldens
+    img, concept, base, tweened = (torch.from_numpy(g[f'concept{k}/{n}']).to(dev)
+                                   for n in ('img', 'concept', 'base', 'tweened'))
+    cm = FG.ConceptMapper(img, concept)
+    assert np.array_equal(cm.map(base).cpu().numpy(), g[f'concept{k}/out_plain'])
+    assert np.array_equal(cm.map(base, tweened.clone()).cpu().numpy(), g[f'concept{k}/out'])
+
+
+def test_errors(dev):
+    from flexdiffuse_amd import guidance as FG
+    a = torch.zeros((1, 10, 48), device=dev)
+    t = torch.zeros((1, 77, 48), device=dev)
+    with pytest.raises(ValueError):
+        FG._map_emb(a, t)          # D % 32 != 0
+    with pytest.raises(RuntimeError):
+        FG._map_emb(a.cpu(), t.cpu())   # no CPU fallback
