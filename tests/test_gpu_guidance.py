@@ -96,9 +96,14 @@ def test_underflow_edge_cases(dev):
     D = 64
     alt = rng.standard_normal((1, 40, D)).astype(np.float32)
     txt = rng.standard_normal((1, 77, D)).astype(np.float32)
-    # every guide token is (nearly) text token 3 -> all other columns underflow to 0
+    # every guide token is (nearly) text token 3 and every other text token points the
+    # opposite way: logits differ by ~200 so all other columns underflow to exactly 0
+    for j in range(77):
+        if j not in (3, 20):
+            txt[0, j] = -txt[0, 3] * (1 + 0.01 * j) + 1e-3 * rng.standard_normal(D).astype(np.float32)
+    txt[0, 20] = txt[0, 3] + 0.3 * rng.standard_normal(D).astype(np.float32)
     for i in range(40):
-        alt[0, i] = txt[0, 3] * (1.0 + 0.01 * i) + 1e-3 * rng.standard_normal(D).astype(np.float32)
+        alt[0, i] = txt[0, 3] * (1.0 + 0.01 * i) + 0.05 * rng.standard_normal(D).astype(np.float32)
     ta, tt = torch.from_numpy(alt).to(dev), torch.from_numpy(txt).to(dev)
     sim = G.similarity(alt, txt)
     assert (sim[:, 10] == 0).all(), 'test construction: expected underflow'
