@@ -1,0 +1,35 @@
+'''Analytic known answers for the DDIM restatement.  CPU only.'''
+import numpy as np
+import torch
+
+from oracle import ddim_ref as D
+
+
+def test_alphas_cumprod_kats():
+    acp = D.alphas_cumprod()
+    kats = {0: 0.99914998, 1: 0.99829602, 20: 0.98131436, 500: 0.27633256, 980: 0.00584377,
+            981: 0.00577549, 999: 0.00466009}
+    for t, v in kats.items():
+        assert abs(acp[t].item() - v) < 5e-8, (t, acp[t].item())
+
+
+def test_timestep_tables():
+    t50 = D.timesteps(50)
+    assert t50[0] == 980 and t50[-1] == 0 and len(t50) == 50 and (np.diff(t50) == -20).all()
+    t50o = D.timesteps(50, steps_offset=1)
+    assert t50o[0] == 981 and t50o[-1] == 1
+    assert list(D.timesteps(10)) == [900, 800, 700, 600, 500, 400, 300, 200, 100, 0]
+    t30 = D.timesteps(30)
+    assert len(t30) == 31 and t30[0] == 990 and t30[1] == 957 and t30[-1] == 0
+
+
+def test_step_invariants():
+    acp = D.alphas_cumprod()
+    x = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(0))
+    out = D.ddim_step(torch.zeros_like(x), 500, x, acp, 50)
+    assert torch.allclose(out, (acp[480] / acp[500]).sqrt() * x, rtol=1e-6, atol=1e-7)
+    last = D.ddim_step(torch.zeros_like(x), 0, x, acp, 50)
+    assert torch.allclose(last, x, rtol=1e-6)      # prev<0 -> alpha_prev = acp[0]
+    n = torch.randn_like(x)
+    noisy = D.add_noise(x, n, 580, acp)
+    assert torch.allclose(noisy, acp[580].sqrt() * x + (1 - acp[580]).sqrt() * n)
