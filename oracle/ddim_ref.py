@@ -10,8 +10,10 @@ import torch
 
 
 def alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012) -> torch.Tensor:
-    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
-    return torch.cumprod(1.0 - betas, dim=0)
+    '''scaled_linear betas; diffusers 0.3.0 schedulers are numpy-float32 based
+    (`set_format('pt')`, pipeline/flex.py:55), so the table is built with numpy.'''
+    betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=np.float32) ** 2
+    return torch.from_numpy(np.cumprod(1.0 - betas, axis=0).astype(np.float32))
 
 
 def timesteps(num_inference_steps: int, n_train=1000, steps_offset=0) -> np.ndarray:
