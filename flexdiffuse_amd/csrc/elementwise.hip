@@ -1,0 +1,301 @@
+// Small HBM-bound kernels around the MFMA path: layout conversion between the pipeline's
+// NCHW fp32 latents and the kernels' NHWC fp16 activations, im2col for the few convs whose
+// input-channel count is below one K tile (conv_in 4ch, VAE conv_in, CLIP patch embed),
+// channel concat for the UNet skip connections, the fused classifier-free-guidance + DDIM
+// update, CLIP token/position embedding gathers and the sinusoidal timestep embedding.
+#include "common.h"
+
+// ---- NCHW fp32 -> NHWC fp16 (optionally replicated `rep` times along batch: CFG) ---------
+__global__ void k_nchw_to_nhwc(const float* __restrict__ x, half_t* __restrict__ y, int B, int C,
+                               int HW, int rep, int Cpad, float scale) {
+    const size_t total = (size_t)B * HW * Cpad;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int c = e % Cpad;
+        const size_t r = e / Cpad;
+        const int p = r % HW;
+        const int b = r / HW;
+        const half_t v = c < C ? (half_t)(x[((size_t)b * C + c) * HW + p] * scale) : (half_t)0.f;
+        for (int k = 0; k < rep; ++k) y[((size_t)(k * B + b) * HW + p) * Cpad + c] = v;
+    }
+}
+
+extern "C" int fd_nchw_f32_to_nhwc_f16(const float* x, void* y, int B, int C, int HW, int rep,
+                                       int c_pad, float scale, void* stream) {
+    FD_CHECK_ARG(x && y && B > 0 && C > 0 && HW > 0 && rep > 0 && c_pad >= C, FD_EINVAL,
+                 "fd_nchw_f32_to_nhwc_f16: args");
+    const size_t total = (size_t)B * HW * c_pad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x,
+                       (half_t*)y, B, C, HW, rep, c_pad, scale);
+    FD_CHECK_LAUNCH("k_nchw_to_nhwc");
+    return FD_OK;
+}
+
+// ---- NHWC fp32 [B][HW][ld] -> NCHW fp32 [B][C][HW]: y = clamp(x*a + b) -------------------
+__global__ void k_nhwc_to_nchw(const float* __restrict__ x, float* __restrict__ y, int B, int C,
+                               int HW, int ld, float a, float bofs, int clamp01) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int p = e % HW;
+        const size_t r = e / HW;
+        const int c = r % C;
+        const int b = r / C;
+        float v = x[((size_t)b * HW + p) * ld + c] * a + bofs;
+        if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+        y[e] = v;
+    }
+}
+
+extern "C" int fd_nhwc_f32_to_nchw_f32(const float* x, float* y, int B, int C, int HW, int ld,
+                                       float a, float b, int clamp01, void* stream) {
+    FD_CHECK_ARG(x && y && B > 0 && C > 0 && HW > 0 && ld >= C, FD_EINVAL,
+                 "fd_nhwc_f32_to_nchw_f32: args");
+    const size_t total = (size_t)B * C * HW;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, B, C,
+                       HW, ld, a, b, clamp01);
+    FD_CHECK_LAUNCH("k_nhwc_to_nchw");
+    return FD_OK;
+}
+
+// ---- im2col (NHWC fp16) for convs with Cin < 64: out[m][k], k=(kh*KW+kw)*Cin+ci, zero pad --
+__global__ void k_im2col(const half_t* __restrict__ x, half_t* __restrict__ y, int B, int Hi, int Wi,
+                         int Cin, int Ho, int Wo, int KH, int KW, int stride, int pad_t, int pad_l,
+                         int Kpad) {
+    const size_t total = (size_t)B * Ho * Wo * Kpad;
+    const int K = KH * KW * Cin;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int k = e % Kpad;
+        const size_t m = e / Kpad;
+        half_t v = (half_t)0.f;
+        if (k < K) {
+            const int ci = k % Cin, tap = k / Cin;
+            const int kh = tap / KW, kw = tap % KW;
+            const int ox = m % Wo;
+            const size_t r = m / Wo;
+            const int oy = r % Ho;
+            const int b = r / Ho;
+            const int iy = oy * stride + kh - pad_t, ix = ox * stride + kw - pad_l;
+            if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi)
+                v = x[(((size_t)b * Hi + iy) * Wi + ix) * Cin + ci];
+        }
+        y[e] = v;
+    }
+}
+
+extern "C" int fd_im2col_f16(const void* x, void* y, int B, int Hi, int Wi, int Cin, int Ho,
+                             int Wo, int KH, int KW, int stride, int pad_t, int pad_l, int k_pad,
+                             void* stream) {
+    FD_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Ho > 0 && Wo > 0, FD_EINVAL,
+                 "fd_im2col_f16: args");
+    FD_CHECK_ARG(k_pad >= KH * KW * Cin && k_pad % 8 == 0, FD_ESHAPE, "fd_im2col_f16: k_pad");
+    const size_t total = (size_t)B * Ho * Wo * k_pad;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_im2col, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                       (half_t*)y, B, Hi, Wi, Cin, Ho, Wo, KH, KW, stride, pad_t, pad_l, k_pad);
+    FD_CHECK_LAUNCH("k_im2col");
+    return FD_OK;
+}
+
+// ---- channel concat of two row-major fp16 matrices: out[m] = [a[m] | b[m]] ---------------
+__global__ void k_concat(const uint4* __restrict__ a, const uint4* __restrict__ b,
+                         uint4* __restrict__ out, size_t M, int ca8, int cb8) {
+    const int ct = ca8 + cb8;
+    const size_t total = M * ct;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int c = e % ct;
+        const size_t m = e / ct;
+        out[e] = c < ca8 ? a[m * ca8 + c] : b[m * cb8 + (c - ca8)];
+    }
+}
+
+extern "C" int fd_concat_channels_f16(const void* a, const void* b, void* out, int64_t M, int Ca,
+                                      int Cb, void* stream) {
+    FD_CHECK_ARG(a && b && out && M > 0, FD_EINVAL, "fd_concat_channels_f16: args");
+    FD_CHECK_ARG(Ca % 8 == 0 && Cb % 8 == 0, FD_ESHAPE, "fd_concat_channels_f16: C %% 8");
+    const size_t total = (size_t)M * (Ca + Cb) / 8;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_concat, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)a,
+                       (const uint4*)b, (uint4*)out, (size_t)M, Ca / 8, Cb / 8);
+    FD_CHECK_LAUNCH("k_concat");
+    return FD_OK;
+}
+
+// ---- fused classifier-free guidance + DDIM (eta = 0) update ---------------------------------
+//   eps = u + g (t - u);  x0 = (x - c1 eps) / c2;  x' = c3 x0 + c4 eps      (all fp32, no FMA)
+// eps comes straight from the UNet's NHWC fp32 output [2B or B][HW][ld]; x is NCHW fp32.
+__global__ void k_cfg_ddim(float* __restrict__ x, const float* __restrict__ eps,
+                           float* __restrict__ eps_out, int B, int C, int HW, int ld, int cfg,
+                           float gscale, float c1, float c2, float c3, float c4, int vpred,
+                           int do_step) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int p = e % HW;
+        const size_t r = e / HW;
+        const int c = r % C;
+        const int b = r / C;
+        float n;
+        if (cfg) {
+            const float u = eps[((size_t)b * HW + p) * ld + c];
+            const float t = eps[((size_t)(B + b) * HW + p) * ld + c];
+            n = __fadd_rn(u, __fmul_rn(gscale, __fsub_rn(t, u)));
+        } else {
+            n = eps[((size_t)b * HW + p) * ld + c];
+        }
+        if (eps_out) eps_out[e] = n;
+        if (do_step) {
+            const float xv = x[e];
+            float x0, en = n;
+            if (vpred) {
+                x0 = __fsub_rn(__fmul_rn(c2, xv), __fmul_rn(c1, n));
+                en = __fadd_rn(__fmul_rn(c2, n), __fmul_rn(c1, xv));
+            } else {
+                x0 = __fdiv_rn(__fsub_rn(xv, __fmul_rn(c1, n)), c2);
+            }
+            x[e] = __fadd_rn(__fmul_rn(c3, x0), __fmul_rn(c4, en));
+        }
+    }
+}
+
+extern "C" int fd_cfg_ddim_step_f32(float* x, const float* eps_nhwc, float* eps_out, int B, int C,
+                                    int HW, int ld, int cfg, float guidance, float c1, float c2,
+                                    float c3, float c4, int v_prediction, int do_step,
+                                    void* stream) {
+    FD_CHECK_ARG(eps_nhwc && B > 0 && C > 0 && HW > 0 && ld >= C, FD_EINVAL,
+                 "fd_cfg_ddim_step_f32: args");
+    FD_CHECK_ARG(!do_step || x, FD_EINVAL, "fd_cfg_ddim_step_f32: x is null");
+    const size_t total = (size_t)B * C * HW;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_cfg_ddim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc,
+                       eps_out, B, C, HW, ld, cfg, guidance, c1, c2, c3, c4, v_prediction, do_step);
+    FD_CHECK_LAUNCH("k_cfg_ddim");
+    return FD_OK;
+}
+
+// ---- out = a*x + b*y (fp32): add_noise, latent scaling, VAE sampling helper ----------------
+__global__ void k_axpby(const float* __restrict__ x, const float* __restrict__ y,
+                        float* __restrict__ out, size_t n, float a, float b, int exp_half_x) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += (size_t)gridDim.x * blockDim.x) {
+        float xv = x[e];
+        if (exp_half_x) xv = expf(0.5f * xv);  // std = exp(0.5 logvar)
+        const float yv = y ? y[e] : 0.f;
+        out[e] = exp_half_x ? __fmul_rn(__fmul_rn(xv, yv), b) : __fadd_rn(__fmul_rn(a, xv), __fmul_rn(b, yv));
+    }
+}
+
+extern "C" int fd_axpby_f32(const float* x, const float* y, float* out, int64_t n, float a,
+                            float b, int exp_half_x, void* stream) {
+    FD_CHECK_ARG(x && out && n > 0, FD_EINVAL, "fd_axpby_f32: args");
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_axpby, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, out,
+                       (size_t)n, a, b, exp_half_x);
+    FD_CHECK_LAUNCH("k_axpby");
+    return FD_OK;
+}
+
+// ---- CLIP text embeddings: out[b][l] = tok[ids[b][l]] + pos[l] --------------------------------
+__global__ void k_embed_tokens(const long long* __restrict__ ids, const half_t* __restrict__ tok,
+                               const half_t* __restrict__ pos, half_t* __restrict__ out, int L,
+                               int D, int vocab) {
+    const int row = blockIdx.x;
+    const int l = row % L;
+    long long id = ids[row];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    for (int d = threadIdx.x; d < D; d += blockDim.x)
+        out[(size_t)row * D + d] =
+            (half_t)((float)tok[(size_t)id * D + d] + (float)pos[(size_t)l * D + d]);
+}
+
+extern "C" int fd_embed_tokens_f16(const int64_t* ids, const void* tok_emb, const void* pos_emb,
+                                   void* out, int B, int L, int D, int vocab, void* stream) {
+    FD_CHECK_ARG(ids && tok_emb && pos_emb && out && B > 0 && L > 0 && D > 0, FD_EINVAL,
+                 "fd_embed_tokens_f16: args");
+    hipLaunchKernelGGL(k_embed_tokens, dim3(B * L), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)ids, (const half_t*)tok_emb, (const half_t*)pos_emb,
+                       (half_t*)out, L, D, vocab);
+    FD_CHECK_LAUNCH("k_embed_tokens");
+    return FD_OK;
+}
+
+// ---- ViT embeddings: out[b][0] = cls + pos[0]; out[b][1+p] = patch[b][p] + pos[1+p] ----------
+__global__ void k_vit_assemble(const half_t* __restrict__ patches, const half_t* __restrict__ cls,
+                               const half_t* __restrict__ pos, half_t* __restrict__ out, int T,
+                               int D) {
+    const int row = blockIdx.x;  // b*T + t
+    const int t = row % T, b = row / T;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        const float v = t == 0 ? (float)cls[d] : (float)patches[((size_t)b * (T - 1) + t - 1) * D + d];
+        out[(size_t)row * D + d] = (half_t)(v + (float)pos[(size_t)t * D + d]);
+    }
+}
+
+extern "C" int fd_vit_assemble_f16(const void* patches, const void* cls, const void* pos, void* out,
+                                   int B, int T, int D, void* stream) {
+    FD_CHECK_ARG(patches && cls && pos && out && B > 0 && T > 1 && D > 0, FD_EINVAL,
+                 "fd_vit_assemble_f16: args");
+    hipLaunchKernelGGL(k_vit_assemble, dim3(B * T), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)patches, (const half_t*)cls, (const half_t*)pos, (half_t*)out,
+                       T, D);
+    FD_CHECK_LAUNCH("k_vit_assemble");
+    return FD_OK;
+}
+
+// ---- sinusoidal timestep embedding (flip_sin_to_cos, shift 0): [cos | sin] -> fp16 -----------
+__global__ void k_timestep_embedding(const float* __restrict__ t, half_t* __restrict__ out, int dim) {
+    const int b = blockIdx.x;
+    const int half_dim = dim / 2;
+    const float tv = t[b];
+    for (int i = threadIdx.x; i < half_dim; i += blockDim.x) {
+        const float freq = expf(-9.210340371976184f * (float)i / (float)half_dim);
+        const float a = tv * freq;
+        out[(size_t)b * dim + i] = (half_t)cosf(a);
+        out[(size_t)b * dim + half_dim + i] = (half_t)sinf(a);
+    }
+}
+
+extern "C" int fd_timestep_embedding_f16(const float* t, void* out, int B, int dim, void* stream) {
+    FD_CHECK_ARG(t && out && B > 0 && dim > 0 && dim % 2 == 0, FD_EINVAL,
+                 "fd_timestep_embedding_f16: args");
+    hipLaunchKernelGGL(k_timestep_embedding, dim3(B), dim3(256), 0, (hipStream_t)stream, t,
+                       (half_t*)out, dim);
+    FD_CHECK_LAUNCH("k_timestep_embedding");
+    return FD_OK;
+}
+
+// ---- fp32 -> fp16 cast of a contiguous buffer (weights upload, embeddings) -------------------
+__global__ void k_cast(const float* __restrict__ x, half_t* __restrict__ y, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += (size_t)gridDim.x * blockDim.x)
+        y[e] = (half_t)x[e];
+}
+
+extern "C" int fd_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream) {
+    FD_CHECK_ARG(x && y && n > 0, FD_EINVAL, "fd_cast_f32_to_f16: args");
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_cast, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (half_t*)y,
+                       (size_t)n);
+    FD_CHECK_LAUNCH("k_cast");
+    return FD_OK;
+}
+
+__global__ void k_cast_back(const half_t* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += (size_t)gridDim.x * blockDim.x)
+        y[e] = (float)x[e];
+}
+
+extern "C" int fd_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream) {
+    FD_CHECK_ARG(x && y && n > 0, FD_EINVAL, "fd_cast_f16_to_f32: args");
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_cast_back, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, y, (size_t)n);
+    FD_CHECK_LAUNCH("k_cast_back");
+    return FD_OK;
+}

@@ -1,0 +1,394 @@
+// fp16 MFMA GEMM / implicit-GEMM convolution for gfx950 (v_mfma_f32_16x16x32_f16).
+//
+//   C[M][N] = epilogue( sum_k A(m,k) * W[n][k] )          fp16 in, fp32 accumulate
+//
+// One kernel family serves every dense contraction of the UNet / VAE / CLIP towers:
+//   * linear / 1x1 conv  : A(m,k) = A[m*lda + k]
+//   * conv KHxKW (NHWC)  : A(m,k) gathered on the fly from the [B][Hi][Wi][Cin] input
+//                          (k = (kh*KW+kw)*Cin + ci), with stride, asymmetric padding and
+//                          an optional fused nearest-2x upsample of the input -- no im2col
+//                          buffer ever touches HBM;
+//   * batched (blockIdx.z) for per-sample attention matmuls of the VAE.
+// Weights are [N][K] row-major (K contiguous), i.e. conv weights are stored
+// [Cout][KH][KW][Cin].
+//
+// Tiling: BM x BN x 64 block tile, 4 wavefronts (2x2), 16x16x32 MFMA fragments, LDS rows
+// of 64 halfs (128 B) XOR-swizzled by (row&7)<<4 so that ds_read_b128 fragment reads are
+// at most 2-way conflicted; global->register->LDS staging with the next tile's loads
+// issued before the current tile's MFMAs (one barrier per K tile, two LDS buffers).
+// Workgroups are remapped so that each XCD (private 4 MiB L2) owns a contiguous range of
+// tiles with the n-tile index fastest: the A panel of an m-tile is reused from L2.
+//
+// Epilogue (fused, no extra HBM round trip): alpha, bias[n], per-sample bias2[b][n]
+// (ResBlock time-embedding add), SiLU / quick-GELU / GELU, GEGLU (x * gelu(gate) on
+// interleaved weight rows), residual add, fp16 or fp32 store, or a transposed store
+// ([b][n][m]) used to emit V^T for the attention kernel.
+#include "common.h"
+
+#define BK 64
+
+enum { MODE_LINEAR = 0, MODE_CONV = 1 };
+
+struct GemmArgs {
+    const half_t* A;
+    const half_t* W;
+    void* C;
+    const float* bias;
+    const float* bias2;
+    const half_t* res;
+    long long strideA, strideW, strideC, strideRes;
+    int M, N, K, lda, ldw, ldc, ldr, ldb2;
+    int mode;
+    int Hi, Wi, Cin, Ho, Wo, KW, stride, pad_t, pad_l, up;
+    int rows_per_batch;
+    int act, out_f32, trans_out;
+    long long strideT;  // per-sample stride of the transposed output
+    int ldt;
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+    switch (act) {
+        case FD_ACT_SILU: return x / (1.0f + __expf(-x));
+        case FD_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+        case FD_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        default: return x;
+    }
+}
+
+template <int BM, int BN, bool TRANS>
+__global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
+    constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile
+    constexpr int MI = WTM / 16, NI = WTN / 16; // 16x16 fragments per wave
+    constexpr int AR = BM / 32, BR = BN / 32;   // 16-byte chunks per thread per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = (BM + BN) * 128;  // bytes per LDS stage: A tile then B tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware tile mapping (blocks round-robin over the 8 XCDs) ----------------
+    const int nb = g.tiles_m * g.tiles_n;
+    int id = blockIdx.x;
+    {
+        const int q = nb >> 3, r = nb & 7, xcd = id & 7, slot = id >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tile_n = id % g.tiles_n, tile_m = id / g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int z = blockIdx.z;
+    const half_t* __restrict__ Ab = g.A + (size_t)z * g.strideA;
+    const half_t* __restrict__ Wb = g.W + (size_t)z * g.strideW;
+
+    // ---- per-thread staging rows ------------------------------------------------------
+    const int ck = tid & 7;    // 16-byte chunk (8 halfs) within the 64-wide K tile
+    const int lr = tid >> 3;   // 0..31
+    int a_off[AR];             // linear: m*lda ; conv: sample base offset
+    int a_y[AR], a_x[AR];      // conv: oy*stride - pad_t, ox*stride - pad_l
+    bool a_ok[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + lr + 32 * i;
+        a_ok[i] = m < g.M;
+        const int mm = a_ok[i] ? m : 0;
+        if (g.mode == MODE_CONV) {
+            const int hw = g.Ho * g.Wo;
+            const int b = mm / hw, rem = mm - b * hw;
+            const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+            a_off[i] = b * g.Hi * g.Wi * g.Cin;
+            a_y[i] = oy * g.stride - g.pad_t;
+            a_x[i] = ox * g.stride - g.pad_l;
+        } else {
+            a_off[i] = mm * g.lda;
+            a_y[i] = a_x[i] = 0;
+        }
+    }
+    int b_off[BR];
+    bool b_ok[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + lr + 32 * i;
+        b_ok[i] = n < g.N;
+        b_off[i] = (b_ok[i] ? n : 0) * g.ldw;
+    }
+
+    uint4 ra[AR], rb[BR];
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    const int Hv = g.up ? g.Hi * 2 : g.Hi, Wv = g.up ? g.Wi * 2 : g.Wi;
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + ck * 8;
+        if (g.mode == MODE_CONV) {
+            const int kbase = kt * BK;
+            const int tap = kbase / g.Cin, ci = kbase - tap * g.Cin + ck * 8;
+            const int kh = tap / g.KW, kw = tap - kh * g.KW;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                int iy = a_y[i] + kh, ix = a_x[i] + kw;
+                const bool ok = a_ok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+                if (g.up) {
+                    iy >>= 1;
+                    ix >>= 1;
+                }
+                ra[i] = ok ? *reinterpret_cast<const uint4*>(
+                                 Ab + (size_t)a_off[i] + (size_t)(iy * g.Wi + ix) * g.Cin + ci)
+                           : zero4;
+            }
+        } else {
+            const bool kok = k < g.K;
+#pragma unroll
+            for (int i = 0; i < AR; ++i)
+                ra[i] = (a_ok[i] && kok)
+                            ? *reinterpret_cast<const uint4*>(Ab + (size_t)a_off[i] + k)
+                            : zero4;
+        }
+        const bool kok = k < g.K;
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            rb[i] = (b_ok[i] && kok) ? *reinterpret_cast<const uint4*>(Wb + (size_t)b_off[i] + k)
+                                     : zero4;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int r = lr + 32 * i;
+            *reinterpret_cast<uint4*>(smem + buf * STAGE + r * 128 + ((ck ^ (r & 7)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int r = lr + 32 * i;
+            *reinterpret_cast<uint4*>(smem + buf * STAGE + BM * 128 + r * 128 + ((ck ^ (r & 7)) << 4)) = rb[i];
+        }
+    };
+
+    floatx4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (g.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 fa[MI], fb[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int r = wm * WTM + i * 16 + fr;
+                fa[i] = *reinterpret_cast<const half8*>(smem + cur * STAGE + r * 128 +
+                                                         (((ks * 4 + fq) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int r = wn * WTN + j * 16 + fr;
+                fb[j] = *reinterpret_cast<const half8*>(smem + cur * STAGE + BM * 128 + r * 128 +
+                                                         (((ks * 4 + fq) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if (TRANS)  // lane: 4 consecutive m for one n
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j],
+                                                                           acc[i][j], 0, 0, 0);
+                    else        // lane: 4 consecutive n for one m
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i],
+                                                                           acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------
+    if (TRANS) {
+        // out[b][n][m_local]: lane holds rows m = base + fq*4 + r for column n = base + fr
+        half_t* __restrict__ T = reinterpret_cast<half_t*>(g.C);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + fr;
+                const int mb = m0 + wm * WTM + i * 16 + fq * 4;
+                if (n >= g.N) continue;
+                const float bn = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mb + r;
+                    if (m >= g.M) continue;
+                    const int b = m / g.rows_per_batch, ml = m - b * g.rows_per_batch;
+                    const float v = act_apply(acc[i][j][r] * g.alpha + bn, g.act);
+                    T[(size_t)z * g.strideC + (size_t)b * g.strideT + (size_t)n * g.ldt + ml] =
+                        (half_t)v;
+                }
+            }
+        return;
+    }
+    const bool geglu = g.act == FD_ACT_GEGLU;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + fr;
+        if (m >= g.M) continue;
+        const int b = m / g.rows_per_batch;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nb0 = n0 + wn * WTN + j * 16 + fq * 4;
+            if (nb0 >= g.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
+            if (g.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb0);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (g.bias2) {
+                const float4 bb =
+                    *reinterpret_cast<const float4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (geglu) {
+                // interleaved rows: even fragment = value, odd fragment = gate
+                if (j & 1) continue;
+                float gt[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gt[r] = acc[i][j + 1 < NI ? j + 1 : j][r] * g.alpha;
+                if (g.bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb0 + 16);
+                    gt[0] += bb.x; gt[1] += bb.y; gt[2] += bb.z; gt[3] += bb.w;
+                }
+                const int no = ((n0 + wn * WTN + j * 16) >> 1) + fq * 4;
+                half4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[r] * act_apply(gt[r], FD_ACT_GELU));
+                *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC +
+                                          (size_t)m * g.ldc + no) = o;
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], g.act);
+            if (g.res) {
+                const half4 rr = *reinterpret_cast<const half4*>(
+                    g.res + (size_t)z * g.strideRes + (size_t)m * g.ldr + nb0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            }
+            if (g.out_f32) {
+                float* C = reinterpret_cast<float*>(g.C) + (size_t)z * g.strideC +
+                           (size_t)m * g.ldc + nb0;
+                if (nb0 + 3 < g.N) {
+                    *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int r = 0; r < 4 && nb0 + r < g.N; ++r) C[r] = v[r];
+                }
+            } else {
+                half_t* C = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC +
+                            (size_t)m * g.ldc + nb0;
+                if (nb0 + 3 < g.N) {
+                    half4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+                    *reinterpret_cast<half4*>(C) = o;
+                } else {
+                    for (int r = 0; r < 4 && nb0 + r < g.N; ++r) C[r] = (half_t)v[r];
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+template <int BM, int BN, bool TRANS>
+static int launch(GemmArgs& g, int batch, hipStream_t st) {
+    g.tiles_m = fd_cdiv(g.M, BM);
+    g.tiles_n = fd_cdiv(g.N, BN);
+    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    static bool configured = false;
+    if (!configured && lds > 64 * 1024) {
+        FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16<BM, BN, TRANS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    dim3 grid(g.tiles_m * g.tiles_n, 1, batch);
+    hipLaunchKernelGGL((k_gemm_f16<BM, BN, TRANS>), grid, dim3(256), lds, st, g);
+    FD_CHECK_LAUNCH("k_gemm_f16");
+    return FD_OK;
+}
+
+extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
+    FD_CHECK_ARG(d && d->A && d->W && d->C, FD_EINVAL, "fd_gemm_f16: null pointer");
+    FD_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, FD_EINVAL, "fd_gemm_f16: M/N/K must be > 0");
+    FD_CHECK_ARG(d->K % 8 == 0 && d->ldw % 8 == 0, FD_ESHAPE,
+                 "fd_gemm_f16: K=%d and ldw=%d must be multiples of 8", d->K, d->ldw);
+    FD_CHECK_ARG(((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->C) % 16 == 0, FD_ESHAPE,
+                 "fd_gemm_f16: pointers must be 16-byte aligned");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const half_t*)d->A;
+    g.W = (const half_t*)d->W;
+    g.C = d->C;
+    g.bias = d->bias;
+    g.bias2 = d->bias2;
+    g.res = (const half_t*)d->residual;
+    g.M = d->M; g.N = d->N; g.K = d->K;
+    g.lda = d->lda; g.ldw = d->ldw; g.ldc = d->ldc; g.ldr = d->ldr;
+    g.ldb2 = d->ld_bias2 > 0 ? d->ld_bias2 : d->N;
+    g.strideA = d->batch_stride_a; g.strideW = d->batch_stride_w;
+    g.strideC = d->batch_stride_c; g.strideRes = d->batch_stride_res;
+    g.rows_per_batch = d->rows_per_sample > 0 ? d->rows_per_sample : d->M;
+    g.act = d->act; g.out_f32 = d->out_f32; g.trans_out = d->trans_out;
+    g.strideT = d->trans_sample_stride; g.ldt = d->trans_ld;
+    g.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+    const int batch = d->batch > 0 ? d->batch : 1;
+    if (d->conv) {
+        g.mode = MODE_CONV;
+        g.Hi = d->in_h; g.Wi = d->in_w; g.Cin = d->in_c; g.Ho = d->out_h; g.Wo = d->out_w;
+        g.KW = d->kw; g.stride = d->stride; g.pad_t = d->pad_t; g.pad_l = d->pad_l;
+        g.up = d->upsample2x;
+        FD_CHECK_ARG(d->in_c % BK == 0, FD_ESHAPE,
+                     "fd_gemm_f16: conv needs Cin %% 64 == 0 (got %d); use fd_im2col_f16", d->in_c);
+        FD_CHECK_ARG(d->K == d->kh * d->kw * d->in_c, FD_EINVAL, "fd_gemm_f16: K != kh*kw*Cin");
+        FD_CHECK_ARG(d->M % (d->out_h * d->out_w) == 0, FD_EINVAL,
+                     "fd_gemm_f16: M is not a multiple of out_h*out_w");
+    } else {
+        FD_CHECK_ARG(d->lda % 8 == 0, FD_ESHAPE, "fd_gemm_f16: lda=%d must be a multiple of 8",
+                     d->lda);
+    }
+    if (g.act == FD_ACT_GEGLU)
+        FD_CHECK_ARG(d->N % 32 == 0 && !d->trans_out && !d->out_f32 && !d->residual, FD_ESHAPE,
+                     "fd_gemm_f16: GEGLU needs N %% 32 == 0, fp16 output, no residual");
+    if (!d->trans_out && !(g.act == FD_ACT_GEGLU))
+        FD_CHECK_ARG(d->ldc % 4 == 0 && (d->N % 4 == 0 || true), FD_ESHAPE,
+                     "fd_gemm_f16: ldc must be a multiple of 4");
+    if (g.bias) FD_CHECK_ARG((uintptr_t)g.bias % 16 == 0, FD_ESHAPE, "fd_gemm_f16: bias align");
+    if (g.res) FD_CHECK_ARG(d->ldr % 4 == 0, FD_ESHAPE, "fd_gemm_f16: ldr must be a multiple of 4");
+
+    hipStream_t st = (hipStream_t)stream;
+    const double flops = 2.0 * (double)d->M * d->N * d->K * batch;
+    fd_prof_begin(FD_FAMILY_GEMM, st, flops);
+    int rc;
+    if (d->trans_out) {
+        rc = launch<128, 64, true>(g, batch, st);
+    } else {
+        // tile choice: fill the 256 CUs first, then prefer the tile with no N waste
+        const long long blocks128 = (long long)fd_cdiv(g.M, 128) * fd_cdiv(g.N, 128) * batch;
+        const bool n160 = (g.N % 160 == 0) && (g.N % 128 != 0) && g.act != FD_ACT_GEGLU;
+        if (g.M <= 64 || blocks128 < 160) {
+            rc = launch<64, 64, false>(g, batch, st);
+        } else if (n160) {
+            rc = launch<128, 160, false>(g, batch, st);
+        } else if (g.N <= 64) {
+            rc = launch<128, 64, false>(g, batch, st);
+        } else {
+            rc = launch<128, 128, false>(g, batch, st);
+        }
+    }
+    fd_prof_end(FD_FAMILY_GEMM, st);
+    return rc;
+}

@@ -1,0 +1,284 @@
+// HBM-bound normalisation kernels for gfx950: GroupNorm(+SiLU) on NHWC fp16 activations,
+// LayerNorm over the channel dimension, and a row softmax (VAE single-head attention).
+// All loads/stores are 16-byte vectors (8 halfs per lane); statistics in fp32/fp64.
+//
+// GroupNorm is two launches over an L2/MALL-resident tensor:
+//   k_gn_stats : grid (chunks, B).  Thread t owns the fixed 8-channel chunk t % (C/8) and
+//                walks pixels t / (C/8), +PL, ... of its slab, so per-channel sums stay in
+//                registers; per-(sample, chunk, group) partial (sum, sumsq) go to a small
+//                fp32 workspace (deterministic, no atomics).
+//   k_gn_apply : grid (chunks, B).  Combines the partials in fp64, folds mean/rstd/gamma/
+//                beta into per-channel (scale, shift) in LDS, then streams the slab:
+//                y = x*scale + shift, optional SiLU.
+// Algorithmic HBM bytes: 2 B read (stats) + 2 B read + 2 B write (apply) per element.
+#include "common.h"
+
+#define GN_MAX_CHUNKS 256
+
+__global__ void k_gn_stats(const half_t* __restrict__ x, float* __restrict__ part, int HW, int C,
+                           int G, int PL, int pix_per_chunk) {
+    extern __shared__ float sm[];  // [PL][C][2]
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int c8 = C >> 3;
+    const int tid = threadIdx.x;
+    const int cc = tid % c8, pl = tid / c8;
+    const int p0 = chunk * pix_per_chunk;
+    const int p1 = min(HW, p0 + pix_per_chunk);
+    float s[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = q[k] = 0.f;
+    if (pl < PL) {
+        const half_t* base = x + ((size_t)b * HW) * C + cc * 8;
+        for (int p = p0 + pl; p < p1; p += PL) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(base + (size_t)p * C);
+            const half8 v = *reinterpret_cast<const half8*>(&raw);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float f = (float)v[k];
+                s[k] += f;
+                q[k] = fmaf(f, f, q[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            sm[((size_t)pl * C + cc * 8 + k) * 2 + 0] = s[k];
+            sm[((size_t)pl * C + cc * 8 + k) * 2 + 1] = q[k];
+        }
+    }
+    __syncthreads();
+    if (tid < G) {
+        const int cpg = C / G;
+        float gs = 0.f, gq = 0.f;
+        for (int l = 0; l < PL; ++l)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                gs += sm[((size_t)l * C + c) * 2 + 0];
+                gq += sm[((size_t)l * C + c) * 2 + 1];
+            }
+        float* dst = part + (((size_t)b * gridDim.x + chunk) * G + tid) * 2;
+        dst[0] = gs;
+        dst[1] = gq;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ x,
+                                                  half_t* __restrict__ y,
+                                                  const float* __restrict__ part,
+                                                  const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int HW, int C,
+                                                  int G, int nchunk_stats, int pix_per_chunk,
+                                                  float eps, int silu) {
+    extern __shared__ float sm[];  // [C] scale, [C] shift, [G] mean, [G] rstd
+    float* sc = sm;
+    float* sh = sm + C;
+    float* gm = sm + 2 * C;
+    float* gr = gm + G;
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int cpg = C / G;
+    if (tid < G) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nchunk_stats; ++k) {
+            const float* src = part + (((size_t)b * nchunk_stats + k) * G + tid) * 2;
+            s += (double)src[0];
+            q += (double)src[1];
+        }
+        const double n = (double)HW * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        gm[tid] = (float)mean;
+        gr[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const float a = gr[g] * gamma[c];
+        sc[c] = a;
+        sh[c] = beta[c] - gm[g] * a;
+    }
+    __syncthreads();
+    const int c8 = C >> 3;
+    const int p0 = chunk * pix_per_chunk;
+    const int p1 = min(HW, p0 + pix_per_chunk);
+    const size_t base = ((size_t)b * HW + p0) * C;
+    const int total = (p1 - p0) * c8;
+    for (int e = tid; e < total; e += 256) {
+        const int c0 = (e % c8) * 8;
+        const uint4 raw = *reinterpret_cast<const uint4*>(x + base + (size_t)e * 8);
+        const half8 v = *reinterpret_cast<const half8*>(&raw);
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float f = fmaf((float)v[k], sc[c0 + k], sh[c0 + k]);
+            if (silu) f = f / (1.0f + __expf(-f));
+            o[k] = (half_t)f;
+        }
+        *reinterpret_cast<uint4*>(y + base + (size_t)e * 8) = *reinterpret_cast<uint4*>(&o);
+    }
+}
+
+extern "C" int64_t fd_groupnorm_workspace_floats(int B, int G) {
+    return (int64_t)B * GN_MAX_CHUNKS * G * 2;
+}
+
+extern "C" int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma,
+                                     const float* beta, float* ws, int B, int HW, int C, int G,
+                                     float eps, int silu, void* stream) {
+    FD_CHECK_ARG(x && y && gamma && beta && ws, FD_EINVAL, "fd_groupnorm_nhwc_f16: null pointer");
+    FD_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0, FD_EINVAL, "fd_groupnorm_nhwc_f16: bad dims");
+    FD_CHECK_ARG(C % 8 == 0 && C % G == 0 && G <= 64, FD_ESHAPE,
+                 "fd_groupnorm_nhwc_f16: C=%d must be a multiple of 8 and of G=%d (G<=64)", C, G);
+    hipStream_t st = (hipStream_t)stream;
+    const int c8 = C / 8;
+    FD_CHECK_ARG(c8 <= 1024, FD_ESHAPE, "fd_groupnorm_nhwc_f16: C=%d too large", C);
+    int PL = 512 / c8;
+    if (PL < 1) PL = 1;
+    if (PL > HW) PL = HW;
+    const int threads = ((c8 * PL + 63) / 64) * 64;
+    int nchunk = 2048 / B;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
+    int ppc = fd_cdiv(HW, nchunk);
+    if (ppc < PL) ppc = PL;
+    nchunk = fd_cdiv(HW, ppc);
+    const size_t lds1 = (size_t)PL * C * 2 * sizeof(float);
+    FD_CHECK_ARG(lds1 <= 64 * 1024, FD_ESHAPE, "fd_groupnorm_nhwc_f16: stats LDS too large");
+    const double bytes = (double)B * HW * C * 6.0;
+    fd_prof_begin(FD_FAMILY_GROUPNORM, st, bytes);
+    hipLaunchKernelGGL(k_gn_stats, dim3(nchunk, B), dim3(threads), lds1, st, (const half_t*)x, ws,
+                       HW, C, G, PL, ppc);
+    const size_t lds2 = (size_t)(2 * C + 2 * G) * sizeof(float);
+    hipLaunchKernelGGL(k_gn_apply, dim3(nchunk, B), dim3(256), lds2, st, (const half_t*)x,
+                       (half_t*)y, ws, gamma, beta, HW, C, G, nchunk, ppc, eps, silu);
+    fd_prof_end(FD_FAMILY_GROUPNORM, st);
+    FD_CHECK_LAUNCH("k_gn_stats/k_gn_apply");
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm over the last dim: one wavefront per row, the row lives in registers, exact
+// two-pass statistics (mean, then sum of squared deviations) with wave shuffles.
+template <int VPL>  // uint4 vectors per lane: C <= 512*VPL
+__global__ __launch_bounds__(256) void k_layernorm(const half_t* __restrict__ x, void* __restrict__ y,
+                                                   const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, int rows, int C,
+                                                   int ldx, int ldy, float eps, int out_f32) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const half_t* xr = x + (size_t)row * ldx;
+    half8 v[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (c < C) raw = *reinterpret_cast<const uint4*>(xr + c);
+        v[i] = *reinterpret_cast<half8*>(&raw);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += (float)v[i][k];
+    }
+    const float mean = fd_wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < C) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float dlt = (float)v[i][k] - mean;
+                sq = fmaf(dlt, dlt, sq);
+            }
+        }
+    }
+    const float rstd = rsqrtf(fd_wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c >= C) continue;
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            o[k] = ((float)v[i][k] - mean) * rstd * gamma[c + k] + beta[c + k];
+        if (out_f32) {
+            float* yr = reinterpret_cast<float*>(y) + (size_t)row * ldy + c;
+            *reinterpret_cast<float4*>(yr) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(yr + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        } else {
+            half8 h;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) h[k] = (half_t)o[k];
+            *reinterpret_cast<uint4*>(reinterpret_cast<half_t*>(y) + (size_t)row * ldy + c) =
+                *reinterpret_cast<uint4*>(&h);
+        }
+    }
+}
+
+extern "C" int fd_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta,
+                                int rows, int C, int ldx, int ldy, float eps, int out_f32,
+                                void* stream) {
+    FD_CHECK_ARG(x && y && gamma && beta && rows > 0 && C > 0, FD_EINVAL, "fd_layernorm_f16: args");
+    FD_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && C <= 2048, FD_ESHAPE,
+                 "fd_layernorm_f16: C=%d must be a multiple of 8 and <= 2048", C);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(fd_cdiv(rows, 4));
+    if (C <= 512)
+        hipLaunchKernelGGL(k_layernorm<1>, grid, dim3(256), 0, st, (const half_t*)x, y, gamma, beta,
+                           rows, C, ldx, ldy, eps, out_f32);
+    else if (C <= 1024)
+        hipLaunchKernelGGL(k_layernorm<2>, grid, dim3(256), 0, st, (const half_t*)x, y, gamma, beta,
+                           rows, C, ldx, ldy, eps, out_f32);
+    else
+        hipLaunchKernelGGL(k_layernorm<4>, grid, dim3(256), 0, st, (const half_t*)x, y, gamma, beta,
+                           rows, C, ldx, ldy, eps, out_f32);
+    FD_CHECK_LAUNCH("k_layernorm");
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Row softmax in place on fp16 [rows][ld] (first N columns), fp32 math, one block per row.
+__global__ __launch_bounds__(256) void k_softmax_rows(half_t* __restrict__ x, int N, int ld,
+                                                      float scale) {
+    __shared__ float red[4];
+    half_t* row = x + (size_t)blockIdx.x * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -INFINITY;
+    for (int c = tid * 8; c < N; c += 2048) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(row + c);
+        const half8 v = *reinterpret_cast<const half8*>(&raw);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m = fmaxf(m, (float)v[k] * scale);
+    }
+    m = fd_wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = tid * 8; c < N; c += 2048) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(row + c);
+        const half8 v = *reinterpret_cast<const half8*>(&raw);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += __expf((float)v[k] * scale - m);
+    }
+    s = fd_wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int c = tid * 8; c < N; c += 2048) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(row + c);
+        const half8 v = *reinterpret_cast<const half8*>(&raw);
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (half_t)(__expf((float)v[k] * scale - m) * inv);
+        *reinterpret_cast<uint4*>(row + c) = *reinterpret_cast<uint4*>(&o);
+    }
+}
+
+extern "C" int fd_softmax_rows_f16(void* x, int rows, int N, int ld, float scale, void* stream) {
+    FD_CHECK_ARG(x && rows > 0 && N > 0, FD_EINVAL, "fd_softmax_rows_f16: args");
+    FD_CHECK_ARG(N % 8 == 0 && ld % 8 == 0, FD_ESHAPE, "fd_softmax_rows_f16: N, ld %% 8");
+    hipLaunchKernelGGL(k_softmax_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, (half_t*)x, N,
+                       ld, scale);
+    FD_CHECK_LAUNCH("k_softmax_rows");
+    return FD_OK;
+}

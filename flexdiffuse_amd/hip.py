@@ -41,6 +41,24 @@ _SIGNATURES = {
                                   ctypes.POINTER(fd_tween_params), P]),
     'fd_guidance_concept_override': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     'fd_guidance_header_pull': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'fd_gemm_f16': (c_int, [P, P]),
+    'fd_attention_f16': (c_int, [P, P]),
+    'fd_groupnorm_workspace_floats': (c_int64, [c_int, c_int]),
+    'fd_groupnorm_nhwc_f16': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    'fd_layernorm_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    'fd_softmax_rows_f16': (c_int, [P, c_int, c_int, c_int, c_float, P]),
+    'fd_nchw_f32_to_nhwc_f16': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    'fd_nhwc_f32_to_nchw_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P]),
+    'fd_im2col_f16': (c_int, [P, P] + [c_int] * 12 + [P]),
+    'fd_concat_channels_f16': (c_int, [P, P, P, c_int64, c_int, c_int, P]),
+    'fd_cfg_ddim_step_f32': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                     c_float, c_float, c_float, c_int, c_int, P]),
+    'fd_axpby_f32': (c_int, [P, P, P, c_int64, c_float, c_float, c_int, P]),
+    'fd_embed_tokens_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'fd_vit_assemble_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    'fd_timestep_embedding_f16': (c_int, [P, P, c_int, c_int, P]),
+    'fd_cast_f32_to_f16': (c_int, [P, P, c_int64, P]),
+    'fd_cast_f16_to_f32': (c_int, [P, P, c_int64, P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -1,0 +1,359 @@
+'''Thin Python front of the C ABI: packs descriptors, allocates outputs with torch (device
+memory + streams only) and launches the HIP kernels.  No arithmetic happens here.'''
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_float, c_int32, c_int64, c_void_p
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import hip
+
+ACT_NONE, ACT_SILU, ACT_QUICK_GELU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3, 4
+FAMILY_GEMM, FAMILY_ATTENTION, FAMILY_GROUPNORM = 0, 1, 2
+
+
+class fd_gemm_desc(ctypes.Structure):
+    _fields_ = [('A', c_void_p), ('W', c_void_p), ('C', c_void_p), ('bias', c_void_p),
+                ('bias2', c_void_p), ('residual', c_void_p),
+                ('M', c_int32), ('N', c_int32), ('K', c_int32),
+                ('lda', c_int32), ('ldw', c_int32), ('ldc', c_int32), ('ldr', c_int32),
+                ('ld_bias2', c_int32), ('rows_per_sample', c_int32), ('act', c_int32),
+                ('out_f32', c_int32), ('alpha', c_float),
+                ('conv', c_int32), ('in_h', c_int32), ('in_w', c_int32), ('in_c', c_int32),
+                ('out_h', c_int32), ('out_w', c_int32), ('kh', c_int32), ('kw', c_int32),
+                ('stride', c_int32), ('pad_t', c_int32), ('pad_l', c_int32),
+                ('upsample2x', c_int32), ('trans_out', c_int32), ('trans_ld', c_int32),
+                ('trans_sample_stride', c_int64), ('batch', c_int32),
+                ('batch_stride_a', c_int64), ('batch_stride_w', c_int64),
+                ('batch_stride_c', c_int64), ('batch_stride_res', c_int64)]
+
+
+class fd_attention_desc(ctypes.Structure):
+    _fields_ = [('Q', c_void_p), ('K', c_void_p), ('Vt', c_void_p), ('O', c_void_p),
+                ('q_sample_stride', c_int64), ('k_sample_stride', c_int64),
+                ('vt_sample_stride', c_int64), ('o_sample_stride', c_int64),
+                ('ldq', c_int32), ('ldk', c_int32), ('ldvt', c_int32), ('ldo', c_int32),
+                ('batch', c_int32), ('heads', c_int32), ('n_q', c_int32), ('n_k', c_int32),
+                ('head_dim', c_int32), ('causal', c_int32), ('scale', c_float)]
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------ weights
+@dataclass
+class LinW:
+    '''[N][K] fp16 weight (K contiguous) + fp32 bias padded to a multiple of 4.'''
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    N: int
+    K: int
+
+
+@dataclass
+class ConvW:
+    w: torch.Tensor               # [Cout][kh*kw*Cin (padded)] fp16
+    bias: Optional[torch.Tensor]
+    cout: int
+    cin: int
+    kh: int
+    kw: int
+    im2col: bool                  # Cin < 64: explicit im2col + GEMM
+    kpad: int
+
+
+def _bias(b: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
+    if b is None:
+        return None
+    n = b.numel()
+    out = torch.zeros(_round_up(n, 4), dtype=torch.float32, device=dev)
+    out[:n] = b.to(dev, torch.float32)
+    return out
+
+
+def prep_linear(w: torch.Tensor, b: Optional[torch.Tensor], dev, k_pad: int = 0) -> LinW:
+    N, K = w.shape
+    kp = max(_round_up(K, 8), k_pad)
+    wd = torch.zeros((N, kp), dtype=torch.float16, device=dev)
+    wd[:, :K] = w.to(dev, torch.float16)
+    return LinW(wd, _bias(b, dev), N, kp)
+
+
+def prep_geglu(w: torch.Tensor, b: torch.Tensor, dev) -> LinW:
+    '''ff.net.0.proj [8C][C]: interleave 16 value rows / 16 gate rows for the fused epilogue.'''
+    n2, K = w.shape
+    half = n2 // 2
+    assert half % 16 == 0
+    wv, wg = w[:half].reshape(half // 16, 16, K), w[half:].reshape(half // 16, 16, K)
+    wi = torch.stack([wv, wg], dim=1).reshape(n2, K)
+    bv, bg = b[:half].reshape(half // 16, 16), b[half:].reshape(half // 16, 16)
+    bi = torch.stack([bv, bg], dim=1).reshape(n2)
+    return prep_linear(wi, bi, dev)
+
+
+def prep_conv(w: torch.Tensor, b: Optional[torch.Tensor], dev, cin_pad: int = 0) -> ConvW:
+    '''[Cout][Cin][kh][kw] -> [Cout][kh][kw][Cin] fp16.  Cin < 64 -> im2col layout (K padded).'''
+    cout, cin, kh, kw = w.shape
+    cin_eff = max(cin, cin_pad)
+    wp = torch.zeros((cout, kh, kw, cin_eff), dtype=torch.float32)
+    wp[..., :cin] = w.permute(0, 2, 3, 1).float()
+    k = kh * kw * cin_eff
+    im2col = cin_eff % 64 != 0
+    kpad = _round_up(k, 64) if im2col else k
+    wd = torch.zeros((cout, kpad), dtype=torch.float16, device=dev)
+    wd[:, :k] = wp.reshape(cout, k).to(dev, torch.float16)
+    return ConvW(wd, _bias(b, dev), cout, cin_eff, kh, kw, im2col, kpad)
+
+
+def f32(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.to(dev, torch.float32).contiguous()
+
+
+def f16(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.to(dev, torch.float16).contiguous()
+
+
+# --------------------------------------------------------------------------- activations
+@dataclass
+class Act:
+    '''NHWC fp16 activation stored as a [B*H*W][C] matrix.'''
+    t: torch.Tensor
+    B: int
+    H: int
+    W: int
+
+    @property
+    def C(self) -> int:
+        return self.t.shape[1]
+
+    @property
+    def HW(self) -> int:
+        return self.H * self.W
+
+
+def _empty(shape, dtype, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ----------------------------------------------------------------------------------- gemm
+def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
+         bias2: Optional[torch.Tensor] = None, ld_bias2: int = 0, rows_per_sample: int = 0,
+         out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0,
+         use_bias: bool = True) -> torch.Tensor:
+    '''a [M][K] fp16 @ w[N][K]^T with fused epilogue -> [M][N] (GEGLU: [M][N/2]).'''
+    M, K = a.shape
+    assert a.dtype == torch.float16 and a.stride(1) == 1 and K == w.K, (a.shape, w.K)
+    n_out = w.N // 2 if act == ACT_GEGLU else w.N
+    if out is None:
+        out = _empty((M, _round_up(n_out, 4)), torch.float32 if out_f32 else torch.float16, a)
+    d = fd_gemm_desc()
+    d.A, d.W, d.C = a.data_ptr(), w.w.data_ptr(), out.data_ptr()
+    d.bias = _p(w.bias) if use_bias else None
+    d.bias2 = _p(bias2)
+    d.residual = _p(residual)
+    d.M, d.N, d.K = M, w.N, K
+    d.lda, d.ldw, d.ldc = a.stride(0), w.w.stride(0), out.stride(0)
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.ld_bias2 = ld_bias2
+    d.rows_per_sample = rows_per_sample
+    d.act, d.out_f32, d.alpha = act, int(out_f32), alpha
+    d.batch = 1
+    hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+    return out
+
+
+def gemm_vt(a: torch.Tensor, w: LinW, B: int, rows_per_sample: int, ld: int) -> torch.Tensor:
+    '''V projection with a transposed store: returns V^T [B][N][ld] fp16 (pad columns zero).'''
+    M, K = a.shape
+    assert M == B * rows_per_sample and K == w.K
+    if ld == rows_per_sample:
+        out = _empty((B, w.N, ld), torch.float16, a)
+    else:
+        out = torch.zeros((B, w.N, ld), dtype=torch.float16, device=a.device)
+    d = fd_gemm_desc()
+    d.A, d.W, d.C = a.data_ptr(), w.w.data_ptr(), out.data_ptr()
+    d.bias = _p(w.bias)
+    d.M, d.N, d.K = M, w.N, K
+    d.lda, d.ldw, d.ldc = a.stride(0), w.w.stride(0), 0
+    d.rows_per_sample = rows_per_sample
+    d.trans_out, d.trans_ld, d.trans_sample_stride = 1, ld, w.N * ld
+    d.alpha, d.batch = 1.0, 1
+    hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+    return out
+
+
+def bgemm(a: torch.Tensor, w: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    '''Batched a[b] [M][K] @ w[b][N][K]^T -> [b][M][N] fp16 (VAE single-head attention).'''
+    Bz, M, K = a.shape
+    N = w.shape[1]
+    out = _empty((Bz, M, N), torch.float16, a)
+    d = fd_gemm_desc()
+    d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldw, d.ldc = a.stride(1), w.stride(1), N
+    d.alpha, d.batch = alpha, Bz
+    d.batch_stride_a, d.batch_stride_w, d.batch_stride_c = a.stride(0), w.stride(0), M * N
+    hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+    return out
+
+
+def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), up: bool = False,
+           out_hw: Optional[Tuple[int, int]] = None, act: int = ACT_NONE,
+           residual: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None,
+           ld_bias2: int = 0, out_f32: bool = False) -> Act:
+    '''NHWC conv (kh x kw) as implicit GEMM; `up` fuses a nearest-2x upsample of the input.'''
+    assert x.C == w.cin, (x.C, w.cin)
+    Hv, Wv = (x.H * 2, x.W * 2) if up else (x.H, x.W)
+    if out_hw is None:
+        Ho = (Hv + 2 * pad[0] - w.kh) // stride + 1
+        Wo = (Wv + 2 * pad[1] - w.kw) // stride + 1
+    else:
+        Ho, Wo = out_hw
+    M = x.B * Ho * Wo
+    out = _empty((M, _round_up(w.cout, 4)), torch.float32 if out_f32 else torch.float16, x.t)
+    d = fd_gemm_desc()
+    d.W, d.C = w.w.data_ptr(), out.data_ptr()
+    d.bias, d.bias2, d.residual = _p(w.bias), _p(bias2), _p(residual)
+    d.M, d.N, d.K = M, w.cout, w.kpad
+    d.ldw, d.ldc = w.w.stride(0), out.stride(0)
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.ld_bias2, d.rows_per_sample = ld_bias2, Ho * Wo
+    d.act, d.out_f32, d.alpha, d.batch = act, int(out_f32), 1.0, 1
+    if w.im2col:
+        assert not up
+        cols = _empty((M, w.kpad), torch.float16, x.t)
+        hip.call('fd_im2col_f16', x.t.data_ptr(), cols.data_ptr(), x.B, x.H, x.W, w.cin, Ho, Wo,
+                 w.kh, w.kw, stride, pad[0], pad[1], w.kpad, hip.stream())
+        d.A, d.lda = cols.data_ptr(), w.kpad
+    else:
+        d.A = x.t.data_ptr()
+        d.conv, d.in_h, d.in_w, d.in_c = 1, x.H, x.W, w.cin
+        d.out_h, d.out_w, d.kh, d.kw = Ho, Wo, w.kh, w.kw
+        d.stride, d.pad_t, d.pad_l, d.upsample2x = stride, pad[0], pad[1], int(up)
+    hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+    return Act(out, x.B, Ho, Wo)
+
+
+# ------------------------------------------------------------------------------ attention
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, heads: int, n_q: int,
+              n_k: int, head_dim: int, causal: bool = False) -> torch.Tensor:
+    '''q [B*n_q][C], k [B*n_k][C], vt [B][C][ldvt] -> [B*n_q][C] fp16.'''
+    out = _empty((B * n_q, heads * head_dim), torch.float16, q)
+    d = fd_attention_desc()
+    d.Q, d.K, d.Vt, d.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(0), k.stride(0), vt.stride(1), out.stride(0)
+    d.q_sample_stride, d.k_sample_stride = n_q * q.stride(0), n_k * k.stride(0)
+    d.vt_sample_stride, d.o_sample_stride = vt.stride(0), n_q * out.stride(0)
+    d.batch, d.heads, d.n_q, d.n_k, d.head_dim = B, heads, n_q, n_k, head_dim
+    d.causal, d.scale = int(causal), 0.0
+    hip.call('fd_attention_f16', ctypes.byref(d), hip.stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------- norms
+_gn_ws = {}
+
+
+def _gn_workspace(B: int, G: int, dev) -> torch.Tensor:
+    n = hip.lib().fd_groupnorm_workspace_floats(B, G)
+    key = (dev.index if dev.index is not None else 0)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(n, dtype=torch.float32, device=dev)
+        _gn_ws[key] = ws
+    return ws
+
+
+def groupnorm(x: Act, gamma: torch.Tensor, beta: torch.Tensor, G: int, eps: float,
+              silu: bool) -> Act:
+    out = torch.empty_like(x.t)
+    assert x.t.is_contiguous()
+    ws = _gn_workspace(x.B, G, x.t.device)
+    hip.call('fd_groupnorm_nhwc_f16', x.t.data_ptr(), out.data_ptr(), gamma.data_ptr(),
+             beta.data_ptr(), ws.data_ptr(), x.B, x.HW, x.C, G, eps, int(silu), hip.stream())
+    return Act(out, x.B, x.H, x.W)
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              out_f32: bool = False) -> torch.Tensor:
+    rows, C = x.shape
+    out = _empty((rows, C), torch.float32 if out_f32 else torch.float16, x)
+    hip.call('fd_layernorm_f16', x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+             rows, C, x.stride(0), out.stride(0), eps, int(out_f32), hip.stream())
+    return out
+
+
+def softmax_rows_(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    rows = x.numel() // x.shape[-1]
+    hip.call('fd_softmax_rows_f16', x.data_ptr(), rows, x.shape[-1], x.stride(-2), scale,
+             hip.stream())
+    return x
+
+
+# ----------------------------------------------------------------------------- elementwise
+def nchw_to_nhwc(x: torch.Tensor, rep: int = 1, c_pad: int = 0, scale: float = 1.0) -> Act:
+    '''fp32 (B,C,H,W) -> NHWC fp16 Act with the batch replicated `rep` times.'''
+    B, C, H, W = x.shape
+    x = x.to(torch.float32).contiguous()
+    cp = max(C, c_pad)
+    out = _empty((rep * B * H * W, cp), torch.float16, x)
+    hip.call('fd_nchw_f32_to_nhwc_f16', x.data_ptr(), out.data_ptr(), B, C, H * W, rep, cp, scale,
+             hip.stream())
+    return Act(out, rep * B, H, W)
+
+
+def nhwc_to_nchw(x: torch.Tensor, B: int, C: int, H: int, W: int, a: float = 1.0, b: float = 0.0,
+                 clamp01: bool = False) -> torch.Tensor:
+    '''fp32 [B*H*W][ld] -> fp32 (B,C,H,W), y = x*a + b.'''
+    assert x.dtype == torch.float32
+    out = _empty((B, C, H, W), torch.float32, x)
+    hip.call('fd_nhwc_f32_to_nchw_f32', x.data_ptr(), out.data_ptr(), B, C, H * W, x.stride(0), a,
+             b, int(clamp01), hip.stream())
+    return out
+
+
+def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    M = a.shape[0]
+    out = _empty((M, a.shape[1] + b.shape[1]), torch.float16, a)
+    hip.call('fd_concat_channels_f16', a.data_ptr(), b.data_ptr(), out.data_ptr(), M, a.shape[1],
+             b.shape[1], hip.stream())
+    return out
+
+
+def cfg_ddim_step(x: Optional[torch.Tensor], eps_nhwc: torch.Tensor, B: int, C: int, HW: int,
+                  cfg: bool, guidance: float, coef=(0.0, 1.0, 1.0, 0.0), v_prediction: bool = False,
+                  do_step: bool = True, eps_out: Optional[torch.Tensor] = None):
+    hip.call('fd_cfg_ddim_step_f32', _p(x), eps_nhwc.data_ptr(), _p(eps_out), B, C, HW,
+             eps_nhwc.stride(0), int(cfg), float(guidance), float(coef[0]), float(coef[1]),
+             float(coef[2]), float(coef[3]), int(v_prediction), int(do_step), hip.stream())
+
+
+def axpby(x: torch.Tensor, y: Optional[torch.Tensor], a: float, b: float,
+          exp_half_x: bool = False) -> torch.Tensor:
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    hip.call('fd_axpby_f32', x.data_ptr(), _p(y.contiguous() if y is not None else None),
+             out.data_ptr(), x.numel(), a, b, int(exp_half_x), hip.stream())
+    return out
+
+
+def cast_f16(x: torch.Tensor) -> torch.Tensor:
+    x = x.to(torch.float32).contiguous()
+    out = _empty(x.shape, torch.float16, x)
+    hip.call('fd_cast_f32_to_f16', x.data_ptr(), out.data_ptr(), x.numel(), hip.stream())
+    return out
+
+
+def cast_f32(x: torch.Tensor) -> torch.Tensor:
+    x = x.contiguous()
+    out = _empty(x.shape, torch.float32, x)
+    hip.call('fd_cast_f16_to_f32', x.data_ptr(), out.data_ptr(), x.numel(), hip.stream())
+    return out

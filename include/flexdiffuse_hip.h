@@ -105,6 +105,110 @@ int fd_guidance_concept_override(const float* guide, const int32_t* cm_idx,
 /* guidance.py:467-472 pure-image path: out[b][0][:] += (hdr[:] - out[b][0][:]) * 0.85 */
 int fd_guidance_header_pull(float* out, const float* hdr, int B, int L, int D, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Dense contractions: fp16 MFMA GEMM / implicit-GEMM convolution with fused epilogue.
+ * Replaces the cuDNN/cuBLAS kernels diffusers/transformers launch inside
+ * `unet(...)` (reference pipeline/guide.py:56-58), `vae.decode/encode`
+ * (pipeline/flex.py:118,189) and the CLIP towers (encode/clip.py:64,86-100).
+ * ---------------------------------------------------------------------------------- */
+#define FD_ACT_NONE 0
+#define FD_ACT_SILU 1
+#define FD_ACT_QUICK_GELU 2 /* x * sigmoid(1.702 x)  (CLIP) */
+#define FD_ACT_GELU 3       /* exact erf GELU */
+#define FD_ACT_GEGLU 4      /* value * gelu(gate); weight rows interleaved 16 value / 16 gate */
+
+typedef struct fd_gemm_desc {
+    const void* A;        /* fp16: linear [M][lda]; conv: NHWC input [B][in_h][in_w][in_c] */
+    const void* W;        /* fp16 [N][ldw], K contiguous (conv: [Cout][kh][kw][Cin]) */
+    void* C;              /* fp16 (or fp32 if out_f32) [M][ldc]; GEGLU: [M][N/2] */
+    const float* bias;    /* [N] or NULL */
+    const float* bias2;   /* per-sample bias [M/rows_per_sample][ld_bias2] or NULL */
+    const void* residual; /* fp16 [M][ldr] added after the activation, or NULL */
+    int32_t M, N, K;
+    int32_t lda, ldw, ldc, ldr, ld_bias2;
+    int32_t rows_per_sample; /* rows of A per sample (H*W or tokens); 0 = M */
+    int32_t act;             /* FD_ACT_* */
+    int32_t out_f32;
+    float alpha;             /* scales the accumulator before bias; 0 means 1 */
+    /* implicit-GEMM convolution (conv != 0): in_c % 64 == 0, K = kh*kw*in_c */
+    int32_t conv, in_h, in_w, in_c, out_h, out_w, kh, kw, stride, pad_t, pad_l, upsample2x;
+    /* transposed store: C is [sample][N][trans_ld] (row n, column m within the sample) */
+    int32_t trans_out, trans_ld;
+    int64_t trans_sample_stride;
+    /* batched GEMM over blockIdx.z: element strides per batch */
+    int32_t batch;
+    int64_t batch_stride_a, batch_stride_w, batch_stride_c, batch_stride_res;
+} fd_gemm_desc;
+
+int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);
+
+/* Flash attention forward (scores never leave registers).  Q [B][n_q][ldq], K [B][n_k][ldk]
+ * with head h at column h*head_dim; Vt [B][heads*head_dim][ldvt] is V transposed (keys
+ * contiguous; columns n_k..ldvt-1 must be finite, e.g. zero); O [B][n_q][ldo].
+ * head_dim % 8 == 0, <= 160.  scale <= 0 means head_dim^-0.5.  causal: key <= query. */
+typedef struct fd_attention_desc {
+    const void* Q;
+    const void* K;
+    const void* Vt;
+    void* O;
+    int64_t q_sample_stride, k_sample_stride, vt_sample_stride, o_sample_stride;
+    int32_t ldq, ldk, ldvt, ldo;
+    int32_t batch, heads, n_q, n_k, head_dim;
+    int32_t causal;
+    float scale;
+} fd_attention_desc;
+
+int fd_attention_f16(const fd_attention_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Normalisation / softmax (HBM-bound)
+ * ---------------------------------------------------------------------------------- */
+int64_t fd_groupnorm_workspace_floats(int B, int G);
+/* GroupNorm(G, eps) [+ SiLU] on NHWC fp16 x [B][HW][C] -> y (may alias x). ws: scratch. */
+int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma, const float* beta,
+                          float* ws, int B, int HW, int C, int G, float eps, int silu,
+                          void* stream);
+/* LayerNorm over the last dim of fp16 x [rows][ldx] -> fp16 (or fp32) y [rows][ldy]. */
+int fd_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int rows,
+                     int C, int ldx, int ldy, float eps, int out_f32, void* stream);
+/* In-place softmax(scale * x) over the first N columns of fp16 x [rows][ld]. */
+int fd_softmax_rows_f16(void* x, int rows, int N, int ld, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Layout / elementwise helpers
+ * ---------------------------------------------------------------------------------- */
+/* NCHW fp32 [B][C][HW] * scale -> NHWC fp16 [rep*B][HW][c_pad] (channels >= C zeroed). */
+int fd_nchw_f32_to_nhwc_f16(const float* x, void* y, int B, int C, int HW, int rep, int c_pad,
+                            float scale, void* stream);
+/* NHWC fp32 [B][HW][ld] -> NCHW fp32 [B][C][HW]: y = x*a + b, optionally clamped to [0,1]. */
+int fd_nhwc_f32_to_nchw_f32(const float* x, float* y, int B, int C, int HW, int ld, float a,
+                            float b, int clamp01, void* stream);
+/* im2col for convolutions with fewer than 64 input channels; out [B*Ho*Wo][k_pad]. */
+int fd_im2col_f16(const void* x, void* y, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int KH,
+                  int KW, int stride, int pad_t, int pad_l, int k_pad, void* stream);
+int fd_concat_channels_f16(const void* a, const void* b, void* out, int64_t M, int Ca, int Cb,
+                           void* stream);
+/* Classifier-free guidance (pipeline/guide.py:59-63) fused with the DDIM update the
+ * reference obtains from scheduler.step (pipeline/flex.py:280-285), eta = 0:
+ *   eps = u + g (t - u); x0 = (x - c1 eps)/c2; x <- c3 x0 + c4 eps
+ * with c1 = sqrt(1-a_t), c2 = sqrt(a_t), c3 = sqrt(a_prev), c4 = sqrt(1-a_prev).
+ * x: NCHW fp32 [B][C][HW] updated in place when do_step; eps_nhwc: UNet output
+ * [(cfg?2:1)*B][HW][ld] fp32 (unconditional half first); eps_out (optional) NCHW fp32. */
+int fd_cfg_ddim_step_f32(float* x, const float* eps_nhwc, float* eps_out, int B, int C, int HW,
+                         int ld, int cfg, float guidance, float c1, float c2, float c3, float c4,
+                         int v_prediction, int do_step, void* stream);
+/* out = a*x + b*y; with exp_half_x: out = exp(0.5 x) * y * b (VAE posterior sampling). */
+int fd_axpby_f32(const float* x, const float* y, float* out, int64_t n, float a, float b,
+                 int exp_half_x, void* stream);
+int fd_embed_tokens_f16(const int64_t* ids, const void* tok_emb, const void* pos_emb, void* out,
+                        int B, int L, int D, int vocab, void* stream);
+int fd_vit_assemble_f16(const void* patches, const void* cls, const void* pos, void* out, int B,
+                        int T, int D, void* stream);
+/* diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0): t [B] fp32 -> fp16 [B][dim]. */
+int fd_timestep_embedding_f16(const float* t, void* out, int B, int dim, void* stream);
+int fd_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
+int fd_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

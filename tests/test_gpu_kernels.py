@@ -1,0 +1,212 @@
+'''Per-kernel numerics of the HIP ops (through the C ABI) against plain PyTorch fp32
+references of the same op on the same fp16-rounded inputs.  Needs an MI355X.
+
+Tolerances: fp16 storage of outputs => relative 2^-10; accumulations are fp32.  Each test
+states its bound.'''
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).half().float()
+
+
+def close(got, want, rtol=2e-3, atol=2e-3):
+    got, want = got.float().cpu(), want.float().cpu()
+    err = (got - want).abs()
+    bound = atol + rtol * want.abs()
+    assert bool((err <= bound).all()), f'max err {err.max().item():.4g} (max |want| {want.abs().max().item():.4g})'
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 320, 320), (1000, 640, 1280), (77, 768, 768),
+                                   (4096, 1280, 640), (130, 36, 72), (64, 8, 8), (16, 20160, 1280)])
+def test_gemm_linear(dev, M, N, K):
+    from flexdiffuse_amd import ops
+    a, w, b = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5), rnd((N,), 3)
+    res = rnd((M, N), 4)
+    lw = ops.prep_linear(w, b, dev)
+    ad = a.half().to(dev)
+    if lw.K != K:
+        ad = F.pad(ad, (0, lw.K - K))
+    out = ops.gemm(ad, lw)
+    close(out[:, :N], a @ w.T + b)
+    out = ops.gemm(ad, lw, act=ops.ACT_SILU, residual=F.pad(res, (0, out.shape[1] - N)).half().to(dev))
+    close(out[:, :N], F.silu(a @ w.T + b) + res)
+    out = ops.gemm(ad, lw, act=ops.ACT_QUICK_GELU, out_f32=True)
+    y = a @ w.T + b
+    close(out[:, :N], y * torch.sigmoid(1.702 * y), rtol=1e-3, atol=1e-3)
+
+
+def test_gemm_bias2_and_geglu(dev):
+    from flexdiffuse_amd import ops
+    B, HW, K, C = 4, 96, 320, 320
+    a, w, b = rnd((B * HW, K), 1), rnd((C, K), 2, K ** -0.5), rnd((C,), 3)
+    b2 = rnd((B, 3 * C), 5)
+    lw = ops.prep_linear(w, b, dev)
+    b2d = b2.to(dev)
+    out = ops.gemm(a.half().to(dev), lw, bias2=b2d[:, C:2 * C], ld_bias2=3 * C, rows_per_sample=HW)
+    want = (a @ w.T + b).view(B, HW, C) + b2[:, None, C:2 * C]
+    close(out, want.view(B * HW, C))
+    # GEGLU: proj [8C][C] -> value * gelu(gate)
+    wg, bg = rnd((8 * C, K), 6, K ** -0.5), rnd((8 * C,), 7)
+    lg = ops.prep_geglu(wg, bg, dev)
+    out = ops.gemm(a.half().to(dev), lg, act=ops.ACT_GEGLU)
+    y = a @ wg.T + bg
+    val, gate = y.chunk(2, dim=-1)
+    assert out.shape == (B * HW, 4 * C)
+    close(out, val * F.gelu(gate), rtol=3e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize('cin,cout,H,W,stride,up', [(64, 128, 16, 16, 1, False),
+                                                   (320, 320, 32, 32, 1, False),
+                                                   (640, 320, 8, 8, 1, True),
+                                                   (128, 64, 16, 24, 2, False),
+                                                   (960, 640, 16, 16, 1, False)])
+def test_conv3x3_implicit(dev, cin, cout, H, W, stride, up):
+    from flexdiffuse_amd import ops
+    B = 3
+    x, w, b = rnd((B, cin, H, W), 1), rnd((cout, cin, 3, 3), 2, (9 * cin) ** -0.5), rnd((cout,), 3)
+    cw = ops.prep_conv(w, b, dev)
+    assert not cw.im2col
+    xa = ops.nchw_to_nhwc(x.to(dev))
+    y = ops.conv2d(xa, cw, stride=stride, up=up)
+    xin = F.interpolate(x, scale_factor=2.0, mode='nearest') if up else x
+    want = F.conv2d(xin, w, b, stride=stride, padding=1)
+    assert (y.H, y.W) == tuple(want.shape[-2:])
+    got = y.t.float().view(B, y.H, y.W, cout).permute(0, 3, 1, 2)
+    close(got, want, rtol=3e-3, atol=3e-3)
+
+
+def test_conv_small_cin_and_asym_pad(dev):
+    from flexdiffuse_amd import ops
+    B, H, W = 2, 16, 16
+    x, w, b = rnd((B, 4, H, W), 1), rnd((320, 4, 3, 3), 2, 1 / 6), rnd((320,), 3)
+    cw = ops.prep_conv(w, b, dev)
+    assert cw.im2col
+    y = ops.conv2d(ops.nchw_to_nhwc(x.to(dev)), cw)
+    close(y.t.float().view(B, H, W, 320).permute(0, 3, 1, 2), F.conv2d(x, w, b, padding=1))
+    # VAE-encoder style: pad (0,1,0,1) then stride-2 conv without padding
+    x, w, b = rnd((B, 128, H, W), 4), rnd((128, 128, 3, 3), 5, (9 * 128) ** -0.5), rnd((128,), 6)
+    cw = ops.prep_conv(w, b, dev)
+    y = ops.conv2d(ops.nchw_to_nhwc(x.to(dev)), cw, stride=2, pad=(0, 0), out_hw=(H // 2, W // 2))
+    want = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    close(y.t.float().view(B, H // 2, W // 2, 128).permute(0, 3, 1, 2), want, rtol=3e-3, atol=3e-3)
+    # conv_out style: N = 4, fp32 output
+    x, w, b = rnd((B, 320, H, W), 7), rnd((4, 320, 3, 3), 8, (9 * 320) ** -0.5), rnd((4,), 9)
+    cw = ops.prep_conv(w, b, dev)
+    y = ops.conv2d(ops.nchw_to_nhwc(x.to(dev)), cw, out_f32=True)
+    got = ops.nhwc_to_nchw(y.t, B, 4, H, W)
+    close(got, F.conv2d(x, w, b, padding=1), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize('C,HW,silu,eps', [(320, 1024, True, 1e-5), (960, 256, True, 1e-5),
+                                           (1280, 64, False, 1e-6), (2560, 64, True, 1e-5),
+                                           (128, 4096, True, 1e-6), (64, 256, False, 1e-6)])
+def test_groupnorm(dev, C, HW, silu, eps):
+    from flexdiffuse_amd import ops
+    B = 3
+    x = rnd((B, C, HW), 1) * 1.5 + 0.7
+    g, b = 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3)
+    xa = ops.Act(x.permute(0, 2, 1).reshape(B * HW, C).half().to(dev).contiguous(), B, HW, 1)
+    y = ops.groupnorm(xa, g.to(dev), b.to(dev), 32, eps, silu)
+    want = F.group_norm(x, 32, g, b, eps)
+    if silu:
+        want = F.silu(want)
+    close(y.t.float().view(B, HW, C).permute(0, 2, 1), want, rtol=3e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize('C', [128, 320, 768, 1280])
+def test_layernorm(dev, C):
+    from flexdiffuse_amd import ops
+    x = rnd((77, C), 1) * 2 + 0.3
+    g, b = 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3)
+    y = ops.layernorm(x.half().to(dev), g.to(dev), b.to(dev), 1e-5, out_f32=True)
+    close(y, F.layer_norm(x, (C,), g, b, 1e-5), rtol=1e-4, atol=1e-4)
+    y = ops.layernorm(x.half().to(dev), g.to(dev), b.to(dev), 1e-5)
+    close(y, F.layer_norm(x, (C,), g, b, 1e-5))
+
+
+def attn_ref(q, k, v, heads, causal=False):
+    B, Nq, C = q.shape
+    d = C // heads
+    qh, kh, vh = (t.view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) * d ** -0.5
+    if causal:
+        s = s + torch.full((Nq, k.shape[1]), float('-inf')).triu(1)
+    return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, C)
+
+
+@pytest.mark.parametrize('Nq,Nk,heads,d,causal', [(256, 256, 8, 40, False), (1024, 1024, 2, 40, False),
+                                                  (256, 77, 8, 40, False), (64, 64, 8, 160, False),
+                                                  (256, 256, 8, 80, False), (100, 77, 8, 160, False),
+                                                  (77, 77, 12, 64, True), (257, 257, 4, 64, False)])
+def test_attention(dev, Nq, Nk, heads, d, causal):
+    from flexdiffuse_amd import ops
+    B, C = 2, heads * d
+    q, k, v = rnd((B, Nq, C), 1), rnd((B, Nk, C), 2), rnd((B, Nk, C), 3)
+    q[0, 3] *= 6.0      # a spiky row: forces large running-max updates across key tiles
+    k[0, Nk - 2] *= 6.0
+    ld = (Nk + 7) // 8 * 8
+    vt = torch.zeros((B, C, ld), dtype=torch.float16)
+    vt[:, :, :Nk] = v.transpose(1, 2).half()
+    out = ops.attention(q.half().to(dev).view(B * Nq, C), k.half().to(dev).view(B * Nk, C),
+                        vt.to(dev), B, heads, Nq, Nk, d, causal)
+    close(out.view(B, Nq, C), attn_ref(q, k, v, heads, causal), rtol=4e-3, atol=4e-3)
+
+
+def test_gemm_transposed_store_feeds_attention(dev):
+    '''V projection written as V^T by the GEMM epilogue, consumed by the attention kernel.'''
+    from flexdiffuse_amd import ops
+    B, N, Cin, heads, d = 2, 77, 768, 8, 40
+    C = heads * d
+    ctx, wv = rnd((B * N, Cin), 1), rnd((C, Cin), 2, Cin ** -0.5)
+    vt = ops.gemm_vt(ctx.half().to(dev), ops.prep_linear(wv, None, dev), B, N, 80)
+    want = (ctx @ wv.T).view(B, N, C).transpose(1, 2)
+    close(vt[:, :, :N], want)
+    assert float(vt[:, :, N:].abs().max()) == 0.0
+
+
+def test_vae_attention_pieces(dev):
+    from flexdiffuse_amd import ops
+    B, N, C = 2, 256, 512
+    q, k = rnd((B, N, C), 1), rnd((B, N, C), 2)
+    s = ops.bgemm(q.half().to(dev), k.half().to(dev), alpha=C ** -0.5)
+    close(s, (q @ k.transpose(1, 2)) * C ** -0.5, rtol=3e-3, atol=3e-3)
+    p = ops.softmax_rows_(s.clone())
+    close(p, ((q @ k.transpose(1, 2)) * C ** -0.5).softmax(-1), rtol=5e-3, atol=2e-4)
+
+
+def test_cfg_ddim_and_layout(dev):
+    from flexdiffuse_amd import ops
+    from oracle import ddim_ref as D
+    B, C, H, W = 3, 4, 8, 8
+    x, eps = rnd((B, C, H, W), 1), rnd((2 * B, C, H, W), 2)
+    acp = D.alphas_cumprod()
+    t, g = 500, 8.0
+    e = eps[:B] + g * (eps[B:] - eps[:B])
+    want = D.ddim_step(e, t, x, acp, 50)
+    a_t, a_p = acp[t], acp[t - 20]
+    coef = (float((1 - a_t).sqrt()), float(a_t.sqrt()), float(a_p.sqrt()), float((1 - a_p).sqrt()))
+    xd = x.to(dev).clone()
+    eps_nhwc = eps.permute(0, 2, 3, 1).reshape(2 * B * H * W, C).contiguous().to(dev)
+    ops.cfg_ddim_step(xd, eps_nhwc, B, C, H * W, True, g, coef)
+    close(xd, want, rtol=1e-6, atol=1e-6)
+    a = ops.nchw_to_nhwc(x.to(dev), rep=2, c_pad=8)
+    assert a.t.shape == (2 * B * H * W, 8)
+    want_nhwc = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    close(a.t[:B * H * W, :C], want_nhwc, rtol=1e-3, atol=1e-3)
+    close(a.t[B * H * W:, :C], want_nhwc, rtol=1e-3, atol=1e-3)
+    assert float(a.t[:, C:].abs().max()) == 0.0
