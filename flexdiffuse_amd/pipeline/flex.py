@@ -1,0 +1,184 @@
+'''Image-guided denoising pipeline -- host-side mirror of the reference's
+`pipeline/flex.py` `FlexPipeline` (ctor :46-83, attention slicing :85-110,
+_latents_to_image :112-124, __call__ :126-310) with the same call signature, return types
+and ValueError, driving the gfx950 kernels.
+
+Device loop: for `SimpleGuide` + DDIM the whole step is  UNet(NHWC fp16, CFG batch built
+inside the layout kernel) -> fused CFG + DDIM update on the fp32 latents  with no host
+round trip; any other guide object goes through the reference protocol
+(`guide.noise_pred` + `scheduler.step`) unchanged.
+
+Deliberate differences: E6 initial noise is drawn on the generator's own
+device -- pass a CPU generator for results independent of the GPU count; E8 `init_image`
+is tested with `is not None`.
+'''
+from __future__ import annotations
+
+import inspect
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .. import hip, ops
+from ..encode.clip import preprocess
+from ..scheduler import DDIMScheduler
+from .guide import GuideBase, SimpleGuide
+
+VAE_SCALE = 0.18215
+
+
+class StableDiffusionPipelineOutput():
+    def __init__(self, images, nsfw_content_detected):
+        self.images = images
+        self.nsfw_content_detected = nsfw_content_detected
+
+    def __getitem__(self, key):
+        if key in ('sample', 'images', 0):
+            return self.images
+        if key in ('nsfw_content_detected', 1):
+            return self.nsfw_content_detected
+        raise KeyError(key)
+
+
+class FlexPipeline():
+    def __init__(self, vae, clip, tokenizer, unet, scheduler):
+        scheduler = scheduler.set_format('pt')
+        self.vae = vae
+        self.clip = clip
+        self.tokenizer = tokenizer
+        self.unet = unet
+        self.scheduler = scheduler
+        self.device = getattr(unet, 'device', torch.device('cuda'))
+        self.last_latents: Optional[torch.Tensor] = None
+        self.last_images: Optional[torch.Tensor] = None
+
+    @classmethod
+    def from_pretrained(cls, *a, **k):
+        raise NotImplementedError('no checkpoints are available offline; build the model '
+                                  'containers from a state dict (see flexdiffuse_amd.build)')
+
+    def to(self, device):
+        self.device = torch.device(device)
+        return self
+
+    def progress_bar(self, iterable):
+        return iterable
+
+    @staticmethod
+    def numpy_to_pil(images: np.ndarray):
+        from PIL import Image
+        if images.ndim == 3:
+            images = images[None, ...]
+        images = (images * 255).round().astype('uint8')
+        return [Image.fromarray(image) for image in images]
+
+    def enable_attention_slicing(self, slice_size: Optional[Union[str, int]] = 'auto'):
+        if slice_size == 'auto':
+            slice_size = self.unet.config['attention_head_dim'] // 2
+        self.unet.set_attention_slice(slice_size)
+
+    def disable_attention_slicing(self):
+        self.enable_attention_slicing(None)
+
+    def decode_latents(self, latents: torch.Tensor) -> torch.Tensor:
+        '''latents -> device image tensor (B,3,H,W) fp32 in [0,1] (pipeline/flex.py:117-120).'''
+        img = self.vae.decode_nhwc(latents, scale=1.0 / VAE_SCALE)
+        return ops.nhwc_to_nchw(img.t, img.B, 3, img.H, img.W, 0.5, 0.5, True)
+
+    def _latents_to_image(self, latents: torch.Tensor, pil: bool = True):
+        image = self.decode_latents(latents)
+        self.last_images = image
+        image = image.cpu().permute(0, 2, 3, 1).numpy()
+        if pil:
+            return self.numpy_to_pil(image)
+        return image
+
+    def _randn(self, shape, generator):
+        gdev = getattr(generator, 'device', torch.device('cpu')) if generator is not None \
+            else torch.device('cpu')
+        return torch.randn(shape, generator=generator, device=gdev,
+                           dtype=torch.float32).to(self.device)
+
+    @torch.no_grad()
+    def __call__(self,
+                 guide: GuideBase,
+                 init_image=None,
+                 init_size: Tuple[int, int] = (512, 512),
+                 strength: float = 0.6,
+                 eta: float = 0.0,
+                 generator: Optional[torch.Generator] = None,
+                 output_type: str = 'pil',
+                 return_dict: bool = True,
+                 debug: bool = False,
+                 latents: Optional[torch.Tensor] = None):
+        if strength < 0 or strength > 1:
+            raise ValueError(
+                f'The value of strength should in [0.0, 1.0] but is {strength}')
+        batch_size = guide.batch_size
+        self.scheduler.set_timesteps(guide.steps)
+        assert self.scheduler.timesteps is not None
+
+        if init_image is not None:
+            if not isinstance(init_image, torch.Tensor):
+                init_image = preprocess(init_image)
+            init_image = init_image.to(self.device)
+            dist = self.vae.encode(init_image).latent_dist
+            init_latents = dist.sample(generator=generator)
+            init_latents = ops.axpby(init_latents, None, VAE_SCALE, 0.0)
+            init_latents = torch.cat([init_latents] * batch_size)
+            offset = self.scheduler.config.get('steps_offset', 0)
+            init_timestep = int(guide.steps * strength) + offset
+            init_timestep = min(init_timestep, guide.steps)
+            t_noise = int(self.scheduler.timesteps[-init_timestep])
+            noise = self._randn(init_latents.shape, generator)
+            init_latents = self.scheduler.add_noise(init_latents, noise, t_noise)
+            t_start = max(guide.steps - init_timestep + offset, 0)
+        else:
+            height, width = init_size
+            channels = self.unet.in_channels
+            shape = (batch_size, channels, height // 8, width // 8)
+            init_latents = self._randn(shape, generator) if latents is None \
+                else latents.to(self.device, torch.float32).clone()
+            self.scheduler.set_timesteps(guide.steps)
+            t_start = 0
+
+        accepts_eta = 'eta' in set(inspect.signature(self.scheduler.step).parameters.keys())
+        extra_step_kwargs = {'eta': eta} if accepts_eta else {}
+
+        latents = init_latents.contiguous()
+        all_latents = [init_latents] if debug else None
+        fused = (type(guide).noise_pred is SimpleGuide.noise_pred
+                 and isinstance(self.scheduler, DDIMScheduler) and not eta
+                 and hasattr(self.unet, 'forward_nhwc'))
+        B, C, H, W = latents.shape
+        for t in self.progress_bar(self.scheduler.timesteps[t_start:]):
+            if fused:
+                cfg = guide.classifier_free_guidance
+                eps = self.unet.forward_nhwc(latents, int(t), guide.stacked_embeds(),
+                                             rep=2 if cfg else 1)
+                coef = self.scheduler.step_coefficients(int(t))[:4]
+                if debug:
+                    latents = latents.clone()
+                ops.cfg_ddim_step(latents, eps, B, C, H * W, cfg, guide.guidance, coef,
+                                  self.scheduler.config['prediction_type'] == 'v_prediction')
+            else:
+                noise_pred = guide.noise_pred(latents, t)
+                latents = self.scheduler.step(noise_pred, t, latents, **extra_step_kwargs).prev_sample
+            if all_latents is not None:
+                all_latents.append(latents)
+        self.last_latents = latents
+
+        if all_latents:
+            batches = [self._latents_to_image(l, output_type == 'pil') for l in all_latents]
+            if isinstance(batches[0], list):
+                batch_images = [im for ib in batches for im in ib]
+            else:
+                batch_images = np.concatenate(batches, axis=0)
+        else:
+            batch_images = self._latents_to_image(latents, output_type == 'pil')
+
+        if not return_dict:
+            return (batch_images, False)
+        return StableDiffusionPipelineOutput(images=batch_images,
+                                             nsfw_content_detected=[False for _ in batch_images])

@@ -1,0 +1,246 @@
+'''Stable-Diffusion UNet on gfx950 -- the container the pipeline receives where the
+reference receives diffusers' `UNet2DConditionModel` (call sites pipeline/guide.py:56-58,
+pipeline/flex.py:101-102,224; SURVEY.md 8b "duck-typed model objects").
+
+Same call surface: `unet(latents, t, encoder_hidden_states=ctx).sample`, `.in_channels`,
+`.config[...]`, `.set_attention_slice(...)`.  Every op is a hand-written HIP kernel behind
+the C ABI (ops.py): implicit-GEMM conv3x3 with fused bias / time-embedding / residual
+epilogues, GroupNorm+SiLU, flash self/cross attention, fused GEGLU.  Activations are NHWC
+fp16, accumulation fp32.  Step-invariant work is hoisted out of the denoising loop: the
+cross-attention K / V^T projections of the text context are cached per context tensor, and
+all 22 ResBlock time-embedding projections are one GEMM per step.
+'''
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+
+from . import hip, ops
+from .ops import Act
+from .weights import SD15_UNET, UNetConfig, unet_param_shapes, unet_up_plan
+
+
+class _Res:
+    def __init__(self, sd, name, dev, temb_off):
+        self.n1g, self.n1b = ops.f32(sd[name + '.norm1.weight'], dev), ops.f32(sd[name + '.norm1.bias'], dev)
+        self.n2g, self.n2b = ops.f32(sd[name + '.norm2.weight'], dev), ops.f32(sd[name + '.norm2.bias'], dev)
+        self.conv1 = ops.prep_conv(sd[name + '.conv1.weight'], sd[name + '.conv1.bias'], dev)
+        self.conv2 = ops.prep_conv(sd[name + '.conv2.weight'], sd[name + '.conv2.bias'], dev)
+        self.short = None
+        if name + '.conv_shortcut.weight' in sd:
+            w = sd[name + '.conv_shortcut.weight']
+            self.short = ops.prep_linear(w.reshape(w.shape[0], w.shape[1]),
+                                         sd[name + '.conv_shortcut.bias'], dev)
+        self.cout = self.conv1.cout
+        self.temb_off = temb_off  # column offset into the fused time-embedding projection
+
+
+class _Attn:
+    def __init__(self, sd, name, dev, heads, linear_proj):
+        g = lambda k: sd[name + k]
+        self.heads = heads
+        self.ng, self.nb = ops.f32(g('.norm.weight'), dev), ops.f32(g('.norm.bias'), dev)
+        w = g('.proj_in.weight')
+        self.proj_in = ops.prep_linear(w.reshape(w.shape[0], w.shape[1]), g('.proj_in.bias'), dev)
+        w = g('.proj_out.weight')
+        self.proj_out = ops.prep_linear(w.reshape(w.shape[0], w.shape[1]), g('.proj_out.bias'), dev)
+        tb = '.transformer_blocks.0'
+        self.ln = [(ops.f32(g(f'{tb}.norm{i}.weight'), dev), ops.f32(g(f'{tb}.norm{i}.bias'), dev))
+                   for i in (1, 2, 3)]
+        self.q1 = ops.prep_linear(g(f'{tb}.attn1.to_q.weight'), None, dev)
+        self.k1 = ops.prep_linear(g(f'{tb}.attn1.to_k.weight'), None, dev)
+        self.v1 = ops.prep_linear(g(f'{tb}.attn1.to_v.weight'), None, dev)
+        self.o1 = ops.prep_linear(g(f'{tb}.attn1.to_out.0.weight'), g(f'{tb}.attn1.to_out.0.bias'), dev)
+        self.q2 = ops.prep_linear(g(f'{tb}.attn2.to_q.weight'), None, dev)
+        self.k2 = ops.prep_linear(g(f'{tb}.attn2.to_k.weight'), None, dev)
+        self.v2 = ops.prep_linear(g(f'{tb}.attn2.to_v.weight'), None, dev)
+        self.o2 = ops.prep_linear(g(f'{tb}.attn2.to_out.0.weight'), g(f'{tb}.attn2.to_out.0.bias'), dev)
+        self.ff1 = ops.prep_geglu(g(f'{tb}.ff.net.0.proj.weight'), g(f'{tb}.ff.net.0.proj.bias'), dev)
+        self.ff2 = ops.prep_linear(g(f'{tb}.ff.net.2.weight'), g(f'{tb}.ff.net.2.bias'), dev)
+        self.C = self.q1.N
+        self.ctx_kv = None  # (K [Be*L][C], V^T [Be][C][ldv]) of the cached text context
+
+
+class UNetOutput(SimpleNamespace):
+    def __getitem__(self, k):
+        return self.sample if k in (0, 'sample') else getattr(self, k)
+
+
+class UNet2DConditionModel():
+    def __init__(self, state_dict: Dict[str, torch.Tensor], config: UNetConfig = SD15_UNET,
+                 device='cuda'):
+        hip.lib()
+        self.cfg = config
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('flexdiffuse_amd.UNet2DConditionModel needs a HIP device '
+                               '(no CPU fallback)')
+        self.in_channels = config.in_channels
+        self.config = {'attention_head_dim': config.num_heads[0], 'in_channels': config.in_channels,
+                       'cross_attention_dim': config.cross_attention_dim,
+                       'block_out_channels': config.block_out_channels}
+        missing = [k for k in unet_param_shapes(config) if k not in state_dict]
+        if missing:
+            raise KeyError(f'UNet state dict is missing {len(missing)} keys, e.g. {missing[:3]}')
+        sd, dev, cfg = state_dict, self.device, config
+        ch = cfg.block_out_channels
+        heads = dict(zip(ch, cfg.num_heads))
+        self.G = cfg.norm_num_groups
+        self.conv_in = ops.prep_conv(sd['conv_in.weight'], sd['conv_in.bias'], dev, cin_pad=8)
+        self.t1 = ops.prep_linear(sd['time_embedding.linear_1.weight'], sd['time_embedding.linear_1.bias'], dev)
+        self.t2 = ops.prep_linear(sd['time_embedding.linear_2.weight'], sd['time_embedding.linear_2.bias'], dev)
+        temb_w, temb_b = [], []
+        self._toff = 0
+
+        def res(name):
+            r = _Res(sd, name, dev, self._toff)
+            temb_w.append(sd[name + '.time_emb_proj.weight'])
+            temb_b.append(sd[name + '.time_emb_proj.bias'])
+            self._toff += r.cout
+            return r
+
+        attn = lambda name, c: _Attn(sd, name, dev, heads[c], cfg.use_linear_projection)
+        self.down: List[dict] = []
+        for i, c in enumerate(ch):
+            blk = {'res': [], 'attn': [], 'down': None}
+            for j in range(cfg.layers_per_block):
+                blk['res'].append(res(f'down_blocks.{i}.resnets.{j}'))
+                blk['attn'].append(attn(f'down_blocks.{i}.attentions.{j}', c) if cfg.cross_attn[i] else None)
+            if i != len(ch) - 1:
+                blk['down'] = ops.prep_conv(sd[f'down_blocks.{i}.downsamplers.0.conv.weight'],
+                                            sd[f'down_blocks.{i}.downsamplers.0.conv.bias'], dev)
+            self.down.append(blk)
+        self.mid_res0 = res('mid_block.resnets.0')
+        self.mid_attn = attn('mid_block.attentions.0', ch[-1])
+        self.mid_res1 = res('mid_block.resnets.1')
+        self.up: List[dict] = []
+        for i, (skips, c, has_attn, has_up) in enumerate(unet_up_plan(cfg)):
+            blk = {'res': [], 'attn': [], 'up': None}
+            for j in range(len(skips)):
+                blk['res'].append(res(f'up_blocks.{i}.resnets.{j}'))
+                blk['attn'].append(attn(f'up_blocks.{i}.attentions.{j}', c) if has_attn else None)
+            if has_up:
+                blk['up'] = ops.prep_conv(sd[f'up_blocks.{i}.upsamplers.0.conv.weight'],
+                                          sd[f'up_blocks.{i}.upsamplers.0.conv.bias'], dev)
+            self.up.append(blk)
+        self.out_g, self.out_b = ops.f32(sd['conv_norm_out.weight'], dev), ops.f32(sd['conv_norm_out.bias'], dev)
+        self.conv_out = ops.prep_conv(sd['conv_out.weight'], sd['conv_out.bias'], dev)
+        # all ResBlock time-embedding projections as ONE [sum(Cout)][temb] GEMM per step
+        self.temb_all = ops.prep_linear(torch.cat(temb_w, 0), torch.cat(temb_b, 0), dev)
+        self.temb_total = self._toff
+        self._attn_layers = [a for blk in self.down for a in blk['attn'] if a] + [self.mid_attn] + \
+                            [a for blk in self.up for a in blk['attn'] if a]
+        self._ctx_key = None
+
+    # ---- reference surface --------------------------------------------------------------
+    def set_attention_slice(self, slice_size):
+        '''No-op: attention is flash-style (scores never materialised), so slicing
+        (pipeline/flex.py:85-110) has nothing to save.'''
+        self.attention_slice = slice_size
+
+    def to(self, device):
+        return self
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, return_dict=True):
+        return self.forward(sample, timestep, encoder_hidden_states)
+
+    # ---- context (step-invariant) -------------------------------------------------------
+    def set_context(self, ctx: torch.Tensor):
+        '''Project the text context through every cross-attention to_k / to_v once.'''
+        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
+        if key == self._ctx_key:
+            return
+        hip.require_device(ctx)
+        Be, L, D = ctx.shape
+        c16 = ops.cast_f16(ctx.reshape(Be * L, D)) if ctx.dtype != torch.float16 \
+            else ctx.reshape(Be * L, D).contiguous()
+        ldv = (L + 7) // 8 * 8
+        for a in self._attn_layers:
+            a.ctx_kv = (ops.gemm(c16, a.k2), ops.gemm_vt(c16, a.v2, Be, L, ldv), L)
+        self._ctx_key = key
+        self._ctx_ref = ctx  # keep the tensor alive so its data_ptr cannot be recycled
+
+    # ---- blocks -----------------------------------------------------------------------------
+    def _res(self, r: _Res, x: Act, temb: torch.Tensor) -> Act:
+        h = ops.groupnorm(x, r.n1g, r.n1b, self.G, 1e-5, True)
+        h = ops.conv2d(h, r.conv1, bias2=temb[:, r.temb_off:r.temb_off + r.cout],
+                       ld_bias2=self.temb_total)
+        h = ops.groupnorm(h, r.n2g, r.n2b, self.G, 1e-5, True)
+        sc = x.t if r.short is None else ops.gemm(x.t, r.short)
+        return ops.conv2d(h, r.conv2, residual=sc)
+
+    def _attn(self, a: _Attn, x: Act) -> Act:
+        B, HW, C = x.B, x.HW, a.C
+        d = C // a.heads
+        h = ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False)
+        h = ops.gemm(h.t, a.proj_in)
+        n = ops.layernorm(h, *a.ln[0])
+        q, k = ops.gemm(n, a.q1), ops.gemm(n, a.k1)
+        vt = ops.gemm_vt(n, a.v1, B, HW, (HW + 7) // 8 * 8)
+        o = ops.attention(q, k, vt, B, a.heads, HW, HW, d)
+        h = ops.gemm(o, a.o1, residual=h)
+        n = ops.layernorm(h, *a.ln[1])
+        kc, vtc, L = a.ctx_kv
+        o = ops.attention(ops.gemm(n, a.q2), kc, vtc, B, a.heads, HW, L, d)
+        h = ops.gemm(o, a.o2, residual=h)
+        n = ops.layernorm(h, *a.ln[2])
+        h = ops.gemm(ops.gemm(n, a.ff1, act=ops.ACT_GEGLU), a.ff2, residual=h)
+        return Act(ops.gemm(h, a.proj_out, residual=x.t), B, x.H, x.W)
+
+    # ---- forward ----------------------------------------------------------------------------
+    def time_bias(self, timestep, B: int) -> torch.Tensor:
+        '''[B][sum Cout] fp32: every ResBlock's Linear(SiLU(time_embedding(t))).'''
+        dev = self.device
+        if isinstance(timestep, torch.Tensor):
+            t = timestep.to(dev, torch.float32).reshape(-1).expand(B).contiguous()
+        else:
+            t = torch.full((B,), float(timestep), dtype=torch.float32, device=dev)
+        dim = self.cfg.block_out_channels[0]
+        e = torch.empty((B, dim), dtype=torch.float16, device=dev)
+        hip.call('fd_timestep_embedding_f16', t.data_ptr(), e.data_ptr(), B, dim, hip.stream())
+        e = ops.gemm(e, self.t1, act=ops.ACT_SILU)
+        e = ops.gemm(e, self.t2, act=ops.ACT_SILU)   # only SiLU(emb) is ever consumed
+        return ops.gemm(e, self.temb_all, out_f32=True)
+
+    def forward_nhwc(self, sample: torch.Tensor, timestep, ctx: torch.Tensor,
+                     rep: int = 1) -> torch.Tensor:
+        '''(B,4,h,w) fp32 latents (replicated `rep` times along batch, e.g. for CFG) ->
+        noise prediction as NHWC fp32 [rep*B*h*w][4].'''
+        hip.require_device(sample, ctx)
+        self.set_context(ctx)
+        x = ops.nchw_to_nhwc(sample, rep=rep, c_pad=self.conv_in.cin)
+        if ctx.shape[0] != x.B:
+            raise ValueError(f'encoder_hidden_states batch {ctx.shape[0]} != latent batch {x.B}')
+        temb = self.time_bias(timestep, x.B)
+        h = ops.conv2d(x, self.conv_in)
+        skips = [h]
+        for blk in self.down:
+            for r, a in zip(blk['res'], blk['attn']):
+                h = self._res(r, h, temb)
+                if a is not None:
+                    h = self._attn(a, h)
+                skips.append(h)
+            if blk['down'] is not None:
+                h = ops.conv2d(h, blk['down'], stride=2)
+                skips.append(h)
+        h = self._res(self.mid_res0, h, temb)
+        h = self._attn(self.mid_attn, h)
+        h = self._res(self.mid_res1, h, temb)
+        for blk in self.up:
+            for r, a in zip(blk['res'], blk['attn']):
+                s = skips.pop()
+                h = Act(ops.concat_channels(h.t, s.t), h.B, h.H, h.W)
+                h = self._res(r, h, temb)
+                if a is not None:
+                    h = self._attn(a, h)
+            if blk['up'] is not None:
+                h = ops.conv2d(h, blk['up'], up=True)
+        h = ops.groupnorm(h, self.out_g, self.out_b, self.G, 1e-5, True)
+        return ops.conv2d(h, self.conv_out, out_f32=True).t
+
+    def forward(self, sample, timestep, encoder_hidden_states) -> UNetOutput:
+        B, C, H, W = sample.shape
+        eps = self.forward_nhwc(sample, timestep, encoder_hidden_states)
+        return UNetOutput(sample=ops.nhwc_to_nchw(eps, B, self.cfg.out_channels, H, W))

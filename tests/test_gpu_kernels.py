@@ -118,7 +118,7 @@ def test_conv_small_cin_and_asym_pad(dev):
 def test_groupnorm(dev, C, HW, silu, eps):
     from flexdiffuse_amd import ops
     B = 3
-    x = rnd((B, C, HW), 1) * 1.5 + 0.7
+    x = (rnd((B, C, HW), 1) * 1.5 + 0.7).half().float()
     g, b = 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3)
     xa = ops.Act(x.permute(0, 2, 1).reshape(B * HW, C).half().to(dev).contiguous(), B, HW, 1)
     y = ops.groupnorm(xa, g.to(dev), b.to(dev), 32, eps, silu)
@@ -131,7 +131,7 @@ def test_groupnorm(dev, C, HW, silu, eps):
 @pytest.mark.parametrize('C', [128, 320, 768, 1280])
 def test_layernorm(dev, C):
     from flexdiffuse_amd import ops
-    x = rnd((77, C), 1) * 2 + 0.3
+    x = (rnd((77, C), 1) * 2 + 0.3).half().float()
     g, b = 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3)
     y = ops.layernorm(x.half().to(dev), g.to(dev), b.to(dev), 1e-5, out_f32=True)
     close(y, F.layer_norm(x, (C,), g, b, 1e-5), rtol=1e-4, atol=1e-4)
@@ -159,6 +159,7 @@ def test_attention(dev, Nq, Nk, heads, d, causal):
     q, k, v = rnd((B, Nq, C), 1), rnd((B, Nk, C), 2), rnd((B, Nk, C), 3)
     q[0, 3] *= 6.0      # a spiky row: forces large running-max updates across key tiles
     k[0, Nk - 2] *= 6.0
+    q, k = q.half().float(), k.half().float()     # keep the inputs fp16-exact
     ld = (Nk + 7) // 8 * 8
     vt = torch.zeros((B, C, ld), dtype=torch.float16)
     vt[:, :, :Nk] = v.transpose(1, 2).half()
