@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+'''Benchmark of the image-guided denoising hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over one batch per GPU (BASELINE.json
+configs[1]): Guide.embeds (CLIP text + ViT image towers, Linear image guidance tween) ->
+50 DDIM steps of the SD1.5 UNet at 512x512 with classifier-free guidance 8, batch 8 per
+GPU -> VAE decode -> (N > 1) RCCL all-gather of final latents and decoded images.
+Weights are seeded synthetic tensors of the exact SD1.5 / CLIP ViT-L/14 architecture and
+inputs are synthetic (no checkpoints or datasets exist offline).  Prints ONE JSON line.
+'''
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2516.6          # MI355X dense fp16 MFMA: 256 CU x 2.4 GHz x 4096 FLOP/clk/CU
+FLOPS_PER_IMAGE = 82.84e12         # BASELINE.md sec. 3, config c2 (100 UNet forwards + VAE decode)
+
+
+def synth_image(seed, w, h):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, (h + 8, w + 8, 3)).astype(np.float32)
+    c = np.pad(np.cumsum(np.cumsum(a, 0), 1), ((1, 0), (1, 0), (0, 0)))
+    blur = ((c[8:, 8:] - c[:-8, 8:] - c[8:, :-8] + c[:-8, :-8]) / 64.0)[:h, :w]
+    blur = (blur - blur.min()) / (blur.max() - blur.min()) * 255.0
+    return Image.fromarray(blur.astype(np.uint8), 'RGB')
+
+
+def synth_prompts(n, seed=1):
+    rng = np.random.default_rng(seed)
+    words = ['photo', 'turtle', 'forest', 'zeus', 'city', 'painting', 'deer', 'storm', 'neon',
+             'ancient', 'river', 'portrait', 'rock', 'monkey', 'anime', 'golden', 'light']
+    return [' '.join(rng.choice(words, size=int(rng.integers(5, 20)))) for _ in range(n)]
+
+
+def cpu_baseline(sds, cfgs, steps):
+    '''Oracle (torch fp32 restatement of the reference path) timed on the host cores over a
+    bounded sample: one CFG UNet evaluation (2 forwards) of ONE image at 64x64 latents plus
+    one 512x512 VAE decode; extrapolated to steps x UNet + decode per image.'''
+    from oracle import unet_ref, vae_ref
+    ucfg, vcfg, _ = cfgs
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 4, 64, 64), generator=g)
+    ctx = torch.randn((2, 77, ucfg.cross_attention_dim), generator=g)
+    t0 = time.time()
+    unet_ref.unet_forward(sds['unet'], ucfg, x, 500, ctx)
+    t_unet = time.time() - t0
+    t0 = time.time()
+    vae_ref.vae_decode(sds['vae'], vcfg, x[:1])
+    t_vae = time.time() - t0
+    per_image = steps * t_unet + t_vae
+    return {'value': 1.0 / per_image, 'unit': 'images/sec', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': f'1 CFG UNet evaluation (2 forwards, 1 image, 64x64 latents) = {t_unet:.2f} s '
+                      f'and 1 VAE decode = {t_vae:.2f} s on {torch.get_num_threads()} threads '
+                      f'({os.cpu_count()} cpus); extrapolated to {steps} steps + decode per image'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU')
+    ap.add_argument('--ddim-steps', type=int, default=50)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--preset', default='sd15')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', local_rank if world > 1 else 0)
+
+    from flexdiffuse_amd import Guide, SimpleGuide, build, hip, ops
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    hip.lib()
+    info = hip.device_info(dev.index or 0)
+
+    t_setup = time.time()
+    sds = build.synthetic_state_dicts(args.preset, seed=0)
+    cfgs = build.configs(args.preset)
+    pipe, clip, tok = build.build_models(sds, args.preset, dev, vae_encoder=False)
+    guide_ctx = Guide(clip, tok, device='cuda')
+    enc = CLIPEncoder(clip, tok)
+    B, N = args.batch, world
+    prompts = synth_prompts(B * N)[rank * B:(rank + 1) * B]
+    guide_img = synth_image(2, 512, 512)
+    hw = args.size
+    noise_all = torch.randn((B * N, 4, hw // 8, hw // 8),
+                            generator=torch.Generator('cpu').manual_seed(1337))
+    noise = noise_all[rank * B:(rank + 1) * B].to(dev)
+    gathered_lat = torch.empty((B * N, 4, hw // 8, hw // 8), dtype=torch.float32, device=dev)
+    t_setup = time.time() - t_setup
+
+    def one_pass():
+        embeds = guide_ctx.embeds(prompt=prompts, guide=guide_img, guide_threshold_mult=0.0,
+                                  guide_clustered=0.0, guide_linear=(0.0, 0.5),
+                                  guide_max_guidance=0.5)
+        sg = SimpleGuide(enc, pipe.unet, 8.0, args.ddim_steps, embeds)
+        out = pipe(guide=sg, init_size=(hw, hw), latents=noise, output_type='np')
+        if world > 1:
+            dist.all_gather_into_tensor(gathered_lat, pipe.last_latents.contiguous())
+            img16 = pipe.last_images.half().contiguous()
+            allimg = torch.empty((B * N,) + tuple(img16.shape[1:]), dtype=torch.float16, device=dev)
+            dist.all_gather_into_tensor(allimg, img16)
+        return out
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        hip.prof_enable(w == args.warmup - 1)   # fills the event pool outside the timed region
+        one_pass()
+        torch.cuda.synchronize()
+        for fam in (ops.FAMILY_GEMM, ops.FAMILY_ATTENTION, ops.FAMILY_GROUPNORM):
+            hip.prof_collect(fam)
+        hip.prof_enable(False)
+
+    sync()
+    t0 = time.time()
+    for k in range(args.steps):
+        if k == args.steps - 1:
+            hip.prof_enable(True)    # HIP events around every launch of the last timed pass
+        one_pass()
+    sync()
+    elapsed = time.time() - t0
+    hip.prof_enable(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    fam = {}
+    for name, code in (('gemm', ops.FAMILY_GEMM), ('attention', ops.FAMILY_ATTENTION),
+                       ('groupnorm', ops.FAMILY_GROUPNORM)):
+        ms, work, n = hip.prof_collect(code)
+        fam[name] = {'ms': ms, 'work': work, 'launches': n}
+
+    if rank == 0:
+        images = B * N * args.steps
+        value = images / elapsed
+        g = fam['gemm']
+        achieved = (g['work'] / (g['ms'] * 1e-3)) / 1e12 if g['ms'] > 0 else 0.0
+        att = fam['attention']
+        gn = fam['groupnorm']
+        line = {
+            'metric': '512x512 50-step images/sec/node (SD1.5, batch=8/GPU, Linear image guidance)',
+            'value': value, 'unit': 'images/sec', 'n_gpus': N, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp16',
+            'data': 'synthetic',
+            'config': {'workload': f'SD1.5 {hw}x{hw} {args.ddim_steps}-step DDIM + Linear image '
+                                   f'guidance, CFG 8, batch={B}/GPU (BASELINE configs[1])',
+                       'images_per_step': B * N, 'parallelism': f'seed-sharded x{N}',
+                       'preset': args.preset},
+            'roofline': {
+                'bound': 'mfma', 'kernel': 'k_gemm_f16 (implicit-GEMM conv3x3 / GEMM family)',
+                'achieved': achieved, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / MFMA_PEAK_TFLOPS, 'traffic': None,
+                'launches': g['launches'], 'kernel_ms_per_pass': g['ms'],
+                'attention_tflops': (att['work'] / (att['ms'] * 1e-3)) / 1e12 if att['ms'] else 0.0,
+                'attention_ms_per_pass': att['ms'],
+                'groupnorm_gbps': (gn['work'] / (gn['ms'] * 1e-3)) / 1e9 if gn['ms'] else 0.0,
+                'groupnorm_ms_per_pass': gn['ms'],
+                'end_to_end_frac_of_mfma_roofline':
+                    (value / N) * FLOPS_PER_IMAGE / (MFMA_PEAK_TFLOPS * 1e12)
+                    if (hw == 512 and args.ddim_steps == 50 and args.preset == 'sd15') else None,
+            },
+            'device': info, 'setup_s': t_setup,
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            sds32 = sds if args.preset != 'sd15' else sds
+            line['cpu_baseline'] = cpu_baseline(sds32, cfgs, args.ddim_steps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -162,7 +162,8 @@ def test_pipeline_end_to_end_psnr(mini, dev):
     steps = 10
     out, pipe, lat_ref, img_ref, used = _run_both(mini, dev, steps, 2, 8.0, 128)
     assert used == [int(t) for t in pipe.scheduler.timesteps] == list(range(900, -1, -100))
-    assert out.images.shape == (2, 128, 128, 3)
+    up = 2 ** (len(mini[4][1].block_out_channels) - 1)      # the mini VAE upsamples x2, not x8
+    assert out.images.shape == (2, 16 * up, 16 * up, 3)
     lat_err = relerr(pipe.last_latents, lat_ref)
     p = pipeline_ref.psnr(pipe.last_images.cpu(), img_ref)
     print(f'latent rel err {lat_err:.4f}, PSNR {p:.1f} dB')
@@ -187,7 +188,7 @@ def test_pipeline_errors_and_outputs(mini, dev):
     with pytest.raises(ValueError):
         pipe(guide=guide, strength=1.5)
     out = pipe(guide=guide, init_size=(64, 64), generator=torch.Generator('cpu').manual_seed(3))
-    assert len(out.images) == 1 and out.images[0].size == (64, 64)
+    assert len(out.images) == 1 and out.images[0].size == (16, 16)   # mini VAE: x2
     assert out['sample'] is out.images and out.nsfw_content_detected == [False]
     imgs, flag = pipe(guide=guide, init_size=(64, 64), return_dict=False, debug=True,
                       generator=torch.Generator('cpu').manual_seed(3))
