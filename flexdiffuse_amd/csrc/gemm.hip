@@ -57,13 +57,17 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     }
 }
 
-template <int BM, int BN, bool TRANS>
+typedef const __attribute__((address_space(1))) half_t* gptr_h;   // force global_load (not flat)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs
+typedef const __attribute__((address_space(1))) u32x4* gptr_u4;
+
+template <int BM, int BN, bool TRANS, bool CONV>
 __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
     constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile
     constexpr int MI = WTM / 16, NI = WTN / 16; // 16x16 fragments per wave
     constexpr int AR = BM / 32, BR = BN / 32;   // 16-byte chunks per thread per tile
+    constexpr int STAGE = (BM + BN) * 128;      // bytes per LDS stage: A tile then B tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE = (BM + BN) * 128;  // bytes per LDS stage: A tile then B tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -78,13 +82,13 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
     const int tile_n = id % g.tiles_n, tile_m = id / g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z;
-    const half_t* __restrict__ Ab = g.A + (size_t)z * g.strideA;
-    const half_t* __restrict__ Wb = g.W + (size_t)z * g.strideW;
+    gptr_h Ab = (gptr_h)g.A + (size_t)z * g.strideA;
+    gptr_h Wb = (gptr_h)g.W + (size_t)z * g.strideW;
 
-    // ---- per-thread staging rows ------------------------------------------------------
+    // ---- per-thread staging rows (fixed for the whole K loop) -------------------------
     const int ck = tid & 7;    // 16-byte chunk (8 halfs) within the 64-wide K tile
     const int lr = tid >> 3;   // 0..31
-    int a_off[AR];             // linear: m*lda ; conv: sample base offset
+    int a_off[AR];             // linear: m*lda + ck*8 ; conv: sample base offset + ck*8
     int a_y[AR], a_x[AR];      // conv: oy*stride - pad_t, ox*stride - pad_l
     bool a_ok[AR];
 #pragma unroll
@@ -92,15 +96,15 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
         const int m = m0 + lr + 32 * i;
         a_ok[i] = m < g.M;
         const int mm = a_ok[i] ? m : 0;
-        if (g.mode == MODE_CONV) {
+        if (CONV) {
             const int hw = g.Ho * g.Wo;
             const int b = mm / hw, rem = mm - b * hw;
             const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
-            a_off[i] = b * g.Hi * g.Wi * g.Cin;
+            a_off[i] = b * g.Hi * g.Wi * g.Cin + ck * 8;
             a_y[i] = oy * g.stride - g.pad_t;
             a_x[i] = ox * g.stride - g.pad_l;
         } else {
-            a_off[i] = mm * g.lda;
+            a_off[i] = mm * g.lda + ck * 8;
             a_y[i] = a_x[i] = 0;
         }
     }
@@ -110,57 +114,67 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
     for (int i = 0; i < BR; ++i) {
         const int n = n0 + lr + 32 * i;
         b_ok[i] = n < g.N;
-        b_off[i] = (b_ok[i] ? n : 0) * g.ldw;
+        b_off[i] = (b_ok[i] ? n : 0) * g.ldw + ck * 8;
+    }
+    int lds_w[AR > BR ? AR : BR];  // swizzled LDS byte offset of this thread's chunk in row i
+#pragma unroll
+    for (int i = 0; i < (AR > BR ? AR : BR); ++i) {
+        const int r = lr + 32 * i;
+        lds_w[i] = r * 128 + ((ck ^ (r & 7)) << 4);
     }
 
-    uint4 ra[AR], rb[BR];
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    u32x4 ra[AR], rb[BR];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int Hv = g.up ? g.Hi * 2 : g.Hi, Wv = g.up ? g.Wi * 2 : g.Wi;
+    const int nk = (g.K + BK - 1) / BK;
+    const int ktail = g.K - ck * 8;  // this thread's chunk is inside K while kt*64 < ktail
+    int kh = 0, kw = 0, ci0 = 0;     // conv: filter tap and channel base of the tile being loaded
 
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + ck * 8;
-        if (g.mode == MODE_CONV) {
-            const int kbase = kt * BK;
-            const int tap = kbase / g.Cin, ci = kbase - tap * g.Cin + ck * 8;
-            const int kh = tap / g.KW, kw = tap - kh * g.KW;
-#pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                int iy = a_y[i] + kh, ix = a_x[i] + kw;
-                const bool ok = a_ok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-                if (g.up) {
-                    iy >>= 1;
-                    ix >>= 1;
-                }
-                ra[i] = ok ? *reinterpret_cast<const uint4*>(
-                                 Ab + (size_t)a_off[i] + (size_t)(iy * g.Wi + ix) * g.Cin + ci)
-                           : zero4;
-            }
-        } else {
-            const bool kok = k < g.K;
-#pragma unroll
-            for (int i = 0; i < AR; ++i)
-                ra[i] = (a_ok[i] && kok)
-                            ? *reinterpret_cast<const uint4*>(Ab + (size_t)a_off[i] + k)
-                            : zero4;
-        }
-        const bool kok = k < g.K;
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-            rb[i] = (b_ok[i] && kok) ? *reinterpret_cast<const uint4*>(Wb + (size_t)b_off[i] + k)
-                                     : zero4;
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int r = lr + 32 * i;
-            *reinterpret_cast<uint4*>(smem + buf * STAGE + r * 128 + ((ck ^ (r & 7)) << 4)) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const int r = lr + 32 * i;
-            *reinterpret_cast<uint4*>(smem + buf * STAGE + BM * 128 + r * 128 + ((ck ^ (r & 7)) << 4)) = rb[i];
-        }
-    };
+    // Unconditional loads from clamped (always valid) addresses + select: no exec-mask
+    // branches around the memory ops, and the waits stay counted (vmcnt) not drained.
+#define GEMM_LOAD_TILE(KT)                                                                  \
+    {                                                                                       \
+        const bool kok = (KT) * BK < ktail;                                                 \
+        const int kofs = kok ? (KT) * BK : 0;                                               \
+        if (CONV) {                                                                         \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                \
+                int iy = a_y[i] + kh, ix = a_x[i] + kw;                                     \
+                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv; \
+                iy = ok ? iy : 0;                                                           \
+                ix = ok ? ix : 0;                                                           \
+                if (g.up) {                                                                 \
+                    iy >>= 1;                                                               \
+                    ix >>= 1;                                                               \
+                }                                                                           \
+                const u32x4 v = *(gptr_u4)(Ab + a_off[i] + (iy * g.Wi + ix) * g.Cin + ci0); \
+                ra[i] = ok ? v : zero4;                                                     \
+            }                                                                               \
+            ci0 += BK;                                                                      \
+            if (ci0 >= g.Cin) {                                                             \
+                ci0 = 0;                                                                    \
+                if (++kw == g.KW) {                                                         \
+                    kw = 0;                                                                 \
+                    ++kh;                                                                   \
+                }                                                                           \
+            }                                                                               \
+        } else {                                                                            \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                \
+                const u32x4 v = *(gptr_u4)(Ab + a_off[i] + kofs);                           \
+                ra[i] = (a_ok[i] && kok) ? v : zero4;                                       \
+            }                                                                               \
+        }                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                    \
+            const u32x4 v = *(gptr_u4)(Wb + b_off[i] + kofs);                               \
+            rb[i] = (b_ok[i] && kok) ? v : zero4;                                           \
+        }                                                                                   \
+    }
+#define GEMM_STORE_TILE(BUF)                                                                \
+    {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < AR; ++i)                                      \
+            *reinterpret_cast<u32x4*>(smem + (BUF) * STAGE + lds_w[i]) = ra[i];             \
+        _Pragma("unroll") for (int i = 0; i < BR; ++i)                                      \
+            *reinterpret_cast<u32x4*>(smem + (BUF) * STAGE + BM * 128 + lds_w[i]) = rb[i];  \
+    }
 
     floatx4 acc[MI][NI];
 #pragma unroll
@@ -168,29 +182,27 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (g.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    GEMM_LOAD_TILE(0);
+    GEMM_STORE_TILE(0);
     __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
+    // fragment read offsets: row r = base + fr, chunk (ks*4 + fq) ^ (r & 7); (r & 7) == (fr & 7)
+    const int frag_a = (wm * WTM + fr) * 128, frag_b = BM * 128 + (wn * WTN + fr) * 128;
+    const int sw0 = ((0 * 4 + fq) ^ (fr & 7)) << 4, sw1 = ((1 * 4 + fq) ^ (fr & 7)) << 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) GEMM_LOAD_TILE(kt + 1);
+        const char* st = smem + cur * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            const int sw = ks ? sw1 : sw0;
             half8 fa[MI], fb[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int r = wm * WTM + i * 16 + fr;
-                fa[i] = *reinterpret_cast<const half8*>(smem + cur * STAGE + r * 128 +
-                                                         (((ks * 4 + fq) ^ (r & 7)) << 4));
-            }
+            for (int i = 0; i < MI; ++i)
+                fa[i] = *reinterpret_cast<const half8*>(st + frag_a + i * 2048 + sw);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int r = wn * WTN + j * 16 + fr;
-                fb[j] = *reinterpret_cast<const half8*>(smem + cur * STAGE + BM * 128 + r * 128 +
-                                                         (((ks * 4 + fq) ^ (r & 7)) << 4));
-            }
+            for (int j = 0; j < NI; ++j)
+                fb[j] = *reinterpret_cast<const half8*>(st + frag_b + j * 2048 + sw);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -203,9 +215,11 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
                                                                            acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if (kt + 1 < nk) GEMM_STORE_TILE(cur ^ 1);
         __syncthreads();
     }
+#undef GEMM_LOAD_TILE
+#undef GEMM_STORE_TILE
 
     // ---- epilogue -----------------------------------------------------------------------
     if (TRANS) {
@@ -304,21 +318,27 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
 }
 
 // --------------------------------------------------------------------------------------
-template <int BM, int BN, bool TRANS>
-static int launch(GemmArgs& g, int batch, hipStream_t st) {
+template <int BM, int BN, bool TRANS, bool CONV>
+static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     g.tiles_m = fd_cdiv(g.M, BM);
     g.tiles_n = fd_cdiv(g.N, BN);
     const size_t lds = 2 * (size_t)(BM + BN) * 128;
     static bool configured = false;
     if (!configured && lds > 64 * 1024) {
-        FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16<BM, BN, TRANS>),
+        FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16<BM, BN, TRANS, CONV>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
     dim3 grid(g.tiles_m * g.tiles_n, 1, batch);
-    hipLaunchKernelGGL((k_gemm_f16<BM, BN, TRANS>), grid, dim3(256), lds, st, g);
+    hipLaunchKernelGGL((k_gemm_f16<BM, BN, TRANS, CONV>), grid, dim3(256), lds, st, g);
     FD_CHECK_LAUNCH("k_gemm_f16");
     return FD_OK;
+}
+
+template <int BM, int BN, bool TRANS>
+static int launch(GemmArgs& g, int batch, hipStream_t st) {
+    return g.mode == MODE_CONV ? launch_mode<BM, BN, TRANS, true>(g, batch, st)
+                               : launch_mode<BM, BN, TRANS, false>(g, batch, st);
 }
 
 extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
