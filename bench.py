@@ -80,15 +80,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    else:
+    from flexdiffuse_amd import dist as fdist
+    rank, world, local_rank = fdist.init('nccl')
+    if world == 1:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local_rank if world > 1 else 0)
 
@@ -104,13 +99,12 @@ def main():
     guide_ctx = Guide(clip, tok, device='cuda')
     enc = CLIPEncoder(clip, tok)
     B, N = args.batch, world
-    prompts = synth_prompts(B * N)[rank * B:(rank + 1) * B]
+    prompts = fdist.shard(synth_prompts(B * N), rank, N, B)
     guide_img = synth_image(2, 512, 512)
     hw = args.size
-    noise_all = torch.randn((B * N, 4, hw // 8, hw // 8),
-                            generator=torch.Generator('cpu').manual_seed(1337))
-    noise = noise_all[rank * B:(rank + 1) * B].to(dev)
-    gathered_lat = torch.empty((B * N, 4, hw // 8, hw // 8), dtype=torch.float32, device=dev)
+    # the whole global batch of noise is drawn once on the host and sliced per rank, so the
+    # images do not depend on the number of GPUs
+    noise = fdist.global_noise(B * N, (4, hw // 8, hw // 8), 1337)[fdist.shard_range(rank, N, B)].to(dev)
     t_setup = time.time() - t_setup
 
     def one_pass():
@@ -119,12 +113,10 @@ def main():
                                   guide_max_guidance=0.5)
         sg = SimpleGuide(enc, pipe.unet, 8.0, args.ddim_steps, embeds)
         out = pipe(guide=sg, init_size=(hw, hw), latents=noise, output_type='np')
-        if world > 1:
-            dist.all_gather_into_tensor(gathered_lat, pipe.last_latents.contiguous())
-            img16 = pipe.last_images.half().contiguous()
-            allimg = torch.empty((B * N,) + tuple(img16.shape[1:]), dtype=torch.float16, device=dev)
-            dist.all_gather_into_tensor(allimg, img16)
-        return out
+        # one RCCL all-gather of the final latents and of the decoded images (identity at N=1)
+        all_latents = fdist.all_gather_samples(pipe.last_latents)
+        all_images = fdist.all_gather_samples(pipe.last_images)
+        return out, all_latents, all_images
 
     def sync():
         if world > 1:

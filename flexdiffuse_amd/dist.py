@@ -1,0 +1,63 @@
+'''Seed / sample sharding across the GPUs of one node.
+
+Samples are independent given (embeddings, initial noise): the denoising loop has no
+cross-sample op (reference pipeline/flex.py:262-287; the reference only ever iterates
+samples sequentially, utils.py:90).  So each rank (one process per GPU) takes a contiguous
+slice of the global batch, weights are replicated, the initial noise is drawn ONCE from a
+host generator and sliced (results do not depend on the world size), and the only
+collective is one all-gather of the final latents / decoded images (RCCL over xGMI through
+torch.distributed's "nccl" backend; "gloo" on CPU in the tests).
+'''
+from __future__ import annotations
+
+import os
+from typing import Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world() -> Tuple[int, int, int]:
+    '''(rank, world_size, local_rank) from the torchrun environment.'''
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')),
+            int(os.environ.get('LOCAL_RANK', '0')))
+
+
+def init(backend: str = 'nccl'):
+    rank, ws, local = world()
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        kw = {}
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            kw['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend, rank=rank, world_size=ws, **kw)
+    return rank, ws, local
+
+
+def shard_range(rank: int, world_size: int, per_rank: int) -> slice:
+    '''Contiguous sample indices of `rank`: [rank*B, (rank+1)*B).'''
+    return slice(rank * per_rank, (rank + 1) * per_rank)
+
+
+def global_noise(total: int, shape: Sequence[int], seed: int) -> torch.Tensor:
+    '''The whole global batch of initial latents from ONE host generator (fp32, CPU).'''
+    return torch.randn((total,) + tuple(shape), generator=torch.Generator('cpu').manual_seed(seed),
+                       dtype=torch.float32)
+
+
+def shard(items, rank: int, world_size: int, per_rank: int):
+    return items[shard_range(rank, world_size, per_rank)]
+
+
+def all_gather_samples(x: torch.Tensor) -> torch.Tensor:
+    '''Concatenate every rank's (B, ...) tensor along dim 0 in rank order (identity when
+    not distributed).'''
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return x
+    x = x.contiguous()
+    out = torch.empty((dist.get_world_size() * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype,
+                      device=x.device)
+    dist.all_gather_into_tensor(out, x)
+    return out
