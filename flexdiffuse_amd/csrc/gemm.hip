@@ -46,6 +46,8 @@ struct GemmArgs {
     int ldt;
     float alpha;
     int tiles_m, tiles_n;
+    int split_k;   // > 1: blockIdx.y owns a K slice and stores fp32 partials to `ws`
+    float* ws;     // [split_k][M][N] fp32
 };
 
 __device__ __forceinline__ float act_apply(float x, int act) {
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
     // ---- per-thread staging rows (fixed for the whole K loop) -------------------------
     const int ck = tid & 7;    // 16-byte chunk (8 halfs) within the 64-wide K tile
     const int lr = tid >> 3;   // 0..31
-    int a_off[AR];             // linear: m*lda + ck*8 ; conv: sample base offset + ck*8
+    int a_off[AR];             // linear: m*lda ; conv: sample base offset + ck*8
     int a_y[AR], a_x[AR];      // conv: oy*stride - pad_t, ox*stride - pad_l
     bool a_ok[AR];
 #pragma unroll
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
             a_y[i] = oy * g.stride - g.pad_t;
             a_x[i] = ox * g.stride - g.pad_l;
         } else {
-            a_off[i] = mm * g.lda + ck * 8;
+            a_off[i] = mm * g.lda;
             a_y[i] = a_x[i] = 0;
         }
     }
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
     for (int i = 0; i < BR; ++i) {
         const int n = n0 + lr + 32 * i;
         b_ok[i] = n < g.N;
-        b_off[i] = (b_ok[i] ? n : 0) * g.ldw + ck * 8;
+        b_off[i] = (b_ok[i] ? n : 0) * g.ldw;
     }
     int lds_w[AR > BR ? AR : BR];  // swizzled LDS byte offset of this thread's chunk in row i
 #pragma unroll
@@ -126,16 +128,25 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
     u32x4 ra[AR], rb[BR];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int Hv = g.up ? g.Hi * 2 : g.Hi, Wv = g.up ? g.Wi * 2 : g.Wi;
-    const int nk = (g.K + BK - 1) / BK;
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int kt_per = (nk_all + g.split_k - 1) / g.split_k;
+    const int kt0 = blockIdx.y * kt_per;                       // this block's K-tile range
+    const int nk = min(nk_all, kt0 + kt_per);
     const int ktail = g.K - ck * 8;  // this thread's chunk is inside K while kt*64 < ktail
     int kh = 0, kw = 0, ci0 = 0;     // conv: filter tap and channel base of the tile being loaded
+    if (CONV && kt0 > 0) {
+        const int tap = (kt0 * BK) / g.Cin;
+        ci0 = kt0 * BK - tap * g.Cin;
+        kh = tap / g.KW;
+        kw = tap - kh * g.KW;
+    }
 
     // Unconditional loads from clamped (always valid) addresses + select: no exec-mask
     // branches around the memory ops, and the waits stay counted (vmcnt) not drained.
 #define GEMM_LOAD_TILE(KT)                                                                  \
     {                                                                                       \
         const bool kok = (KT) * BK < ktail;                                                 \
-        const int kofs = kok ? (KT) * BK : 0;                                               \
+        const int kofs = kok ? (KT) * BK + ck * 8 : 0; /* never read past a row's K */      \
         if (CONV) {                                                                         \
             _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                \
                 int iy = a_y[i] + kh, ix = a_x[i] + kw;                                     \
@@ -182,15 +193,15 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    GEMM_LOAD_TILE(0);
+    GEMM_LOAD_TILE(kt0);
     GEMM_STORE_TILE(0);
     __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
     // fragment read offsets: row r = base + fr, chunk (ks*4 + fq) ^ (r & 7); (r & 7) == (fr & 7)
     const int frag_a = (wm * WTM + fr) * 128, frag_b = BM * 128 + (wn * WTN + fr) * 128;
     const int sw0 = ((0 * 4 + fq) ^ (fr & 7)) << 4, sw1 = ((1 * 4 + fq) ^ (fr & 7)) << 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
         if (kt + 1 < nk) GEMM_LOAD_TILE(kt + 1);
         const char* st = smem + cur * STAGE;
 #pragma unroll
@@ -221,6 +232,27 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
 #undef GEMM_LOAD_TILE
 #undef GEMM_STORE_TILE
 
+    // ---- split-K: raw fp32 partial tile, reduced + finished by k_splitk_finish ------------
+    if (g.split_k > 1) {
+        float* __restrict__ P = g.ws + (size_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + fr;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int nb0 = n0 + wn * WTN + j * 16 + fq * 4;
+                if (nb0 >= g.N) continue;
+                if (nb0 + 3 < g.N) {
+                    *reinterpret_cast<float4*>(P + (size_t)m * g.N + nb0) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                } else {
+                    for (int r = 0; r < 4 && nb0 + r < g.N; ++r) P[(size_t)m * g.N + nb0 + r] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue -----------------------------------------------------------------------
     if (TRANS) {
         // out[b][n][m_local]: lane holds rows m = base + fq*4 + r for column n = base + fr
@@ -317,6 +349,47 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
     }
 }
 
+// Sums the split-K partial slabs in a fixed order and applies the fused epilogue.
+__global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs g) {
+    const int n4 = g.N >> 2;
+    const size_t total = (size_t)g.M * n4;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int m = (int)(e / n4), nb0 = (int)(e - (size_t)m * n4) * 4;
+        float4 a = *reinterpret_cast<const float4*>(g.ws + (size_t)m * g.N + nb0);
+        for (int s = 1; s < g.split_k; ++s) {
+            const float4 p =
+                *reinterpret_cast<const float4*>(g.ws + ((size_t)s * g.M + m) * g.N + nb0);
+            a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+        }
+        float v[4] = {a.x * g.alpha, a.y * g.alpha, a.z * g.alpha, a.w * g.alpha};
+        if (g.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb0);
+            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+        if (g.bias2) {
+            const int b = m / g.rows_per_batch;
+            const float4 bb = *reinterpret_cast<const float4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
+            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], g.act);
+        if (g.res) {
+            const half4 rr = *reinterpret_cast<const half4*>(g.res + (size_t)m * g.ldr + nb0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+        }
+        if (g.out_f32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + nb0) =
+                make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            half4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+            *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(g.C) + (size_t)m * g.ldc + nb0) = o;
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------
 template <int BM, int BN, bool TRANS, bool CONV>
 static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
@@ -329,7 +402,7 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    dim3 grid(g.tiles_m * g.tiles_n, 1, batch);
+    dim3 grid(g.tiles_m * g.tiles_n, g.split_k, batch);
     hipLaunchKernelGGL((k_gemm_f16<BM, BN, TRANS, CONV>), grid, dim3(256), lds, st, g);
     FD_CHECK_LAUNCH("k_gemm_f16");
     return FD_OK;
@@ -391,23 +464,61 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
 
     hipStream_t st = (hipStream_t)stream;
     const double flops = 2.0 * (double)d->M * d->N * d->K * batch;
-    fd_prof_begin(FD_FAMILY_GEMM, st, flops);
+    g.split_k = 1;
+    g.ws = (float*)d->workspace;
     int rc;
     if (d->trans_out) {
+        fd_prof_begin(FD_FAMILY_GEMM, st, flops);
         rc = launch<128, 64, true>(g, batch, st);
+        fd_prof_end(FD_FAMILY_GEMM, st);
+        return rc;
+    }
+    // ---- tile / split-K selection (deterministic; rules fitted to an exhaustive sweep of
+    // every (tile, split_k) over all GEMM shapes of the SD1.5 UNet + VAE on MI355X,
+    // scratch/sweep_gemm.py, profiles/r01_gemm_sweep.txt):
+    //  * 128x160 has the best fragment reuse (up to 860 TFLOP/s) whenever 160 | N (all UNet
+    //    widths); 128x128 otherwise (VAE widths);
+    //  * short-K GEMMs (the transformer projections) are latency- not MFMA-bound: 128x64 with
+    //    3 workgroups per CU wins;
+    //  * when the tile count cannot fill 2 workgroups on each of the 256 CUs, split K until it
+    //    does (fp32 slabs + fixed-order finish kernel, so results stay deterministic).
+    const bool geglu = g.act == FD_ACT_GEGLU;
+    const int nk_all = (g.K + BK - 1) / BK;
+    const bool n160 = (g.N % 160 == 0) && !geglu;
+    const long long tiles_wide =
+        (long long)fd_cdiv(g.M, 128) * (n160 ? fd_cdiv(g.N, 160) : fd_cdiv(g.N, 128)) * batch;
+    int best_tile, best_split = 1;
+    if (g.N <= 64 || g.K <= 640 || (g.K <= 1280 && tiles_wide < 512)) {
+        best_tile = (g.M <= 64) ? 4 : 3;
     } else {
-        // tile choice: fill the 256 CUs first, then prefer the tile with no N waste
-        const long long blocks128 = (long long)fd_cdiv(g.M, 128) * fd_cdiv(g.N, 128) * batch;
-        const bool n160 = (g.N % 160 == 0) && (g.N % 128 != 0) && g.act != FD_ACT_GEGLU;
-        if (g.M <= 64 || blocks128 < 160) {
-            rc = launch<64, 64, false>(g, batch, st);
-        } else if (n160) {
-            rc = launch<128, 160, false>(g, batch, st);
-        } else if (g.N <= 64) {
-            rc = launch<128, 64, false>(g, batch, st);
-        } else {
-            rc = launch<128, 128, false>(g, batch, st);
+        best_tile = n160 ? 2 : 1;
+        if (!geglu && batch == 1 && g.N % 4 == 0 && g.ws) {
+            while (tiles_wide * best_split < 448 && best_split < 16 &&
+                   nk_all / (best_split * 2) >= 4 &&
+                   (size_t)(best_split * 2) * g.M * g.N * 4 <= (size_t)d->workspace_bytes)
+                best_split *= 2;
         }
+    }
+    if (d->tile) best_tile = d->tile;
+    if (d->split_k > 0) best_split = d->split_k;
+    if (best_split > 1)
+        FD_CHECK_ARG(!geglu && batch == 1 && g.N % 4 == 0 && g.ws &&
+                         (size_t)best_split * g.M * g.N * 4 <= (size_t)d->workspace_bytes,
+                     FD_ESHAPE, "fd_gemm_f16: split_k=%d not possible for this problem", best_split);
+    if (geglu && best_tile == 2) best_tile = 1;
+    g.split_k = best_split;
+    fd_prof_begin(FD_FAMILY_GEMM, st, flops);
+    switch (best_tile) {
+        case 2: rc = launch<128, 160, false>(g, batch, st); break;
+        case 3: rc = launch<128, 64, false>(g, batch, st); break;
+        case 4: rc = launch<64, 64, false>(g, batch, st); break;
+        default: rc = launch<128, 128, false>(g, batch, st); break;
+    }
+    if (rc == FD_OK && g.split_k > 1) {
+        const size_t total = (size_t)g.M * (g.N / 4);
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(k_splitk_finish, dim3(blocks), dim3(256), 0, st, g);
+        FD_CHECK_LAUNCH("k_splitk_finish");
     }
     fd_prof_end(FD_FAMILY_GEMM, st);
     return rc;

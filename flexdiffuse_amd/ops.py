@@ -28,7 +28,9 @@ class fd_gemm_desc(ctypes.Structure):
                 ('upsample2x', c_int32), ('trans_out', c_int32), ('trans_ld', c_int32),
                 ('trans_sample_stride', c_int64), ('batch', c_int32),
                 ('batch_stride_a', c_int64), ('batch_stride_w', c_int64),
-                ('batch_stride_c', c_int64), ('batch_stride_res', c_int64)]
+                ('batch_stride_c', c_int64), ('batch_stride_res', c_int64),
+                ('tile', c_int32), ('split_k', c_int32), ('workspace', c_void_p),
+                ('workspace_bytes', c_int64)]
 
 
 class fd_attention_desc(ctypes.Structure):
@@ -144,6 +146,22 @@ def _empty(shape, dtype, like: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------------- gemm
+_splitk_ws = {}
+SPLITK_WS_BYTES = 96 << 20
+FORCE_TILE = 0      # debugging / tuning knobs (0 = library cost model)
+FORCE_SPLIT = 0
+
+
+def _sched(d: 'fd_gemm_desc', dev: torch.device):
+    key = dev.index if dev.index is not None else 0
+    ws = _splitk_ws.get(key)
+    if ws is None:
+        ws = torch.empty(SPLITK_WS_BYTES, dtype=torch.uint8, device=dev)
+        _splitk_ws[key] = ws
+    d.workspace, d.workspace_bytes = ws.data_ptr(), SPLITK_WS_BYTES
+    d.tile, d.split_k = FORCE_TILE, FORCE_SPLIT
+
+
 def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
          bias2: Optional[torch.Tensor] = None, ld_bias2: int = 0, rows_per_sample: int = 0,
          out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0,
@@ -166,6 +184,7 @@ def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[to
     d.rows_per_sample = rows_per_sample
     d.act, d.out_f32, d.alpha = act, int(out_f32), alpha
     d.batch = 1
+    _sched(d, a.device)
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     return out
 
@@ -238,6 +257,7 @@ def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), 
         d.conv, d.in_h, d.in_w, d.in_c = 1, x.H, x.W, w.cin
         d.out_h, d.out_w, d.kh, d.kw = Ho, Wo, w.kh, w.kw
         d.stride, d.pad_t, d.pad_l, d.upsample2x = stride, pad[0], pad[1], int(up)
+    _sched(d, x.t.device)
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     return Act(out, x.B, Ho, Wo)
 

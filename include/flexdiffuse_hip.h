@@ -138,6 +138,12 @@ typedef struct fd_gemm_desc {
     /* batched GEMM over blockIdx.z: element strides per batch */
     int32_t batch;
     int64_t batch_stride_a, batch_stride_w, batch_stride_c, batch_stride_res;
+    /* scheduling: tile 0 = auto, 1 = 128x128, 2 = 128x160, 3 = 128x64, 4 = 64x64; split_k 0 =
+     * auto (needs `workspace`, fp32 [split_k][M][N]), 1 = off. Results are deterministic for
+     * a given (shape, tile, split_k). */
+    int32_t tile, split_k;
+    void* workspace;
+    int64_t workspace_bytes;
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);
