@@ -38,8 +38,8 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
     constexpr int VROWS = DV * 16;
     constexpr int KLD = (64 * KCH + 255) / 256;  // K chunks per thread
     constexpr int VLD = (VROWS * 8 + 255) / 256; // V^T chunks per thread
-    __shared__ __attribute__((aligned(16))) char sK[64 * KSTR];
-    __shared__ __attribute__((aligned(16))) char sV[VROWS * VSTR];
+    constexpr int KBYTES = 64 * KSTR, VBYTES = VROWS * VSTR;
+    __shared__ __attribute__((aligned(16))) char sKV[2 * (KBYTES + VBYTES)];  // two stages
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
                 rv[i] = *reinterpret_cast<const uint4*>(Vb + (size_t)row * a.ldvt + key0 + c * 8);
         }
     };
-    auto store_kv = [&]() {
+    auto store_kv = [&](int buf) {
+        char* sK = sKV + buf * (KBYTES + VBYTES);
+        char* sV = sK + KBYTES;
 #pragma unroll
         for (int i = 0; i < KLD; ++i) {
             const int e = tid + 256 * i;
@@ -126,11 +128,16 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
     };
 
     load_kv(0);
-    store_kv();
+    store_kv(0);
     __syncthreads();
+    const float c2 = a.scale_log2;
 
     for (int j = 0; j < ntiles; ++j) {
         if (j + 1 < ntiles) load_kv(j + 1);
+        const char* sK = sKV + (j & 1) * (KBYTES + VBYTES);
+        const char* sV = sK + KBYTES;
+        // masking is needed only on a ragged last tile or under the causal mask (wave-uniform)
+        const bool need_mask = (j * 64 + 64 > a.Nk) || a.causal;
         // ---- S^T tile: 64 keys x (QT x 16) queries ---------------------------------------
         floatx4 s[4][QT];
 #pragma unroll
@@ -152,29 +159,34 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             const int q = q0 + t * 16 + fr;
-            float tmax = -INFINITY;
+            if (need_mask) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+                for (int f = 0; f < 4; ++f)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = j * 64 + f * 16 + g * 4 + r;
-                    float x = s[f][t][r] * a.scale_log2;
-                    if (key >= a.Nk || (a.causal && key > q)) x = -INFINITY;
-                    s[f][t][r] = x;
-                    tmax = fmaxf(tmax, x);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = j * 64 + f * 16 + g * 4 + r;
+                        if (key >= a.Nk || (a.causal && key > q)) s[f][t][r] = -INFINITY;
+                    }
+            }
+            float tmax = fmaxf(fmaxf(s[0][t][0], s[0][t][1]), fmaxf(s[0][t][2], s[0][t][3]));
+#pragma unroll
+            for (int f = 1; f < 4; ++f)
+                tmax = fmaxf(fmaxf(tmax, fmaxf(s[f][t][0], s[f][t][1])),
+                             fmaxf(s[f][t][2], s[f][t][3]));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            // running max kept in raw-score units; p = 2^(s*c2 - m*c2) as one fma + v_exp_f32
             const float mnew = fmaxf(mrow[t], tmax);
-            const float alpha = (mnew == -INFINITY) ? 1.f : exp2f(mrow[t] - mnew);
-            const float msub = (mnew == -INFINITY) ? 0.f : mnew;
+            const bool dead = mnew == -INFINITY;
+            const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f((mrow[t] - mnew) * c2);
+            const float mc = dead ? 0.f : mnew * c2;
             mrow[t] = mnew;
             float psum = 0.f;
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(s[f][t][r] - msub);
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[f][t][r], c2, -mc));
                     psum += e;
                     p[f >> 1][t][(f & 1) * 4 + r] = (half_t)e;
                 }
@@ -195,11 +207,8 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
                 for (int t = 0; t < QT; ++t)
                     o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, p[kg][t], o[t][dt], 0, 0, 0);
             }
+        if (j + 1 < ntiles) store_kv((j + 1) & 1);
         __syncthreads();
-        if (j + 1 < ntiles) {
-            store_kv();
-            __syncthreads();
-        }
     }
 
     // ---- normalise and store: lane holds O^T[d = dt*16 + g*4 + r][query fr] ---------------

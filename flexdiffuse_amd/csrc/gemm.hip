@@ -23,6 +23,8 @@
 // (ResBlock time-embedding add), SiLU / quick-GELU / GELU, GEGLU (x * gelu(gate) on
 // interleaved weight rows), residual add, fp16 or fp32 store, or a transposed store
 // ([b][n][m]) used to emit V^T for the attention kernel.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define BK 64
@@ -56,6 +58,130 @@ __device__ __forceinline__ float act_apply(float x, int act) {
         case FD_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
         case FD_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
         default: return x;
+    }
+}
+
+// Fused epilogue shared by the register-staged and the LDS-DMA main loops.
+template <int BM, int BN, bool TRANS>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
+                                              floatx4 (&acc)[BM / 32][BN / 32], int m0, int n0,
+                                              int wm, int wn, int fr, int fq, int z) {
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    // ---- split-K: raw fp32 partial tile, reduced + finished by k_splitk_finish ------------
+    if (g.split_k > 1) {
+        float* __restrict__ P = g.ws + (size_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + fr;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int nb0 = n0 + wn * WTN + j * 16 + fq * 4;
+                if (nb0 >= g.N) continue;
+                if (nb0 + 3 < g.N) {
+                    *reinterpret_cast<float4*>(P + (size_t)m * g.N + nb0) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                } else {
+                    for (int r = 0; r < 4 && nb0 + r < g.N; ++r) P[(size_t)m * g.N + nb0 + r] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
+    // ---- epilogue -----------------------------------------------------------------------
+    if (TRANS) {
+        // out[b][n][m_local]: lane holds rows m = base + fq*4 + r for column n = base + fr
+        half_t* __restrict__ T = reinterpret_cast<half_t*>(g.C);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + fr;
+                const int mb = m0 + wm * WTM + i * 16 + fq * 4;
+                if (n >= g.N) continue;
+                const float bn = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mb + r;
+                    if (m >= g.M) continue;
+                    const int b = m / g.rows_per_batch, ml = m - b * g.rows_per_batch;
+                    const float v = act_apply(acc[i][j][r] * g.alpha + bn, g.act);
+                    T[(size_t)z * g.strideC + (size_t)b * g.strideT + (size_t)n * g.ldt + ml] =
+                        (half_t)v;
+                }
+            }
+        return;
+    }
+    const bool geglu = g.act == FD_ACT_GEGLU;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + fr;
+        if (m >= g.M) continue;
+        const int b = m / g.rows_per_batch;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nb0 = n0 + wn * WTN + j * 16 + fq * 4;
+            if (nb0 >= g.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
+            if (g.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb0);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (g.bias2) {
+                const float4 bb =
+                    *reinterpret_cast<const float4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (geglu) {
+                // interleaved rows: even fragment = value, odd fragment = gate
+                if (j & 1) continue;
+                float gt[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gt[r] = acc[i][j + 1 < NI ? j + 1 : j][r] * g.alpha;
+                if (g.bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb0 + 16);
+                    gt[0] += bb.x; gt[1] += bb.y; gt[2] += bb.z; gt[3] += bb.w;
+                }
+                const int no = ((n0 + wn * WTN + j * 16) >> 1) + fq * 4;
+                half4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[r] * act_apply(gt[r], FD_ACT_GELU));
+                *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC +
+                                          (size_t)m * g.ldc + no) = o;
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], g.act);
+            if (g.res) {
+                const half4 rr = *reinterpret_cast<const half4*>(
+                    g.res + (size_t)z * g.strideRes + (size_t)m * g.ldr + nb0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            }
+            if (g.out_f32) {
+                float* C = reinterpret_cast<float*>(g.C) + (size_t)z * g.strideC +
+                           (size_t)m * g.ldc + nb0;
+                if (nb0 + 3 < g.N) {
+                    *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int r = 0; r < 4 && nb0 + r < g.N; ++r) C[r] = v[r];
+                }
+            } else {
+                half_t* C = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC +
+                            (size_t)m * g.ldc + nb0;
+                if (nb0 + 3 < g.N) {
+                    half4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+                    *reinterpret_cast<half4*>(C) = o;
+                } else {
+                    for (int r = 0; r < 4 && nb0 + r < g.N; ++r) C[r] = (half_t)v[r];
+                }
+            }
+        }
     }
 }
 
@@ -232,121 +358,176 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
 #undef GEMM_LOAD_TILE
 #undef GEMM_STORE_TILE
 
-    // ---- split-K: raw fp32 partial tile, reduced + finished by k_splitk_finish ------------
-    if (g.split_k > 1) {
-        float* __restrict__ P = g.ws + (size_t)blockIdx.y * g.M * g.N;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * WTM + i * 16 + fr;
-            if (m >= g.M) continue;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int nb0 = n0 + wn * WTN + j * 16 + fq * 4;
-                if (nb0 >= g.N) continue;
-                if (nb0 + 3 < g.N) {
-                    *reinterpret_cast<float4*>(P + (size_t)m * g.N + nb0) =
-                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                } else {
-                    for (int r = 0; r < 4 && nb0 + r < g.N; ++r) P[(size_t)m * g.N + nb0 + r] = acc[i][j][r];
-                }
-            }
-        }
-        return;
+    gemm_epilogue<BM, BN, TRANS>(g, acc, m0, n0, wm, wn, fr, fq, z);
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS-DMA main loop: tiles go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds), no VGPR
+// staging and no ds_write pass.  One wave instruction moves 64 lanes x 16 B = 8 rows of the
+// 128-byte-row tile; the LDS image is lane-linear, so the XOR swizzle is applied to the
+// per-lane SOURCE chunk (lane slot p of row r loads chunk p ^ (r & 7)) and the fragment reads
+// use the same involution.  Out-of-tile rows, conv zero padding and the K tail are produced
+// by the buffer descriptor's bounds check (an offset past num_records reads 0), so there is
+// no select or branch on the load path.  The K-tile offset rides in the scalar soffset, so
+// per-lane address math only runs when the filter tap changes.
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void k_gemm_f16_dma(GemmArgs g, unsigned a_bytes, unsigned w_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)  // body uses device-only builtins (host pass sees a stub)
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    constexpr int AR = BM / 32, BR = BN / 32;   // DMA instructions per wave per tile
+    constexpr int STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nb = g.tiles_m * g.tiles_n;
+    int id = blockIdx.x;
+    {
+        const int q = nb >> 3, r = nb & 7, xcd = id & 7, slot = id >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    // ---- epilogue -----------------------------------------------------------------------
-    if (TRANS) {
-        // out[b][n][m_local]: lane holds rows m = base + fq*4 + r for column n = base + fr
-        half_t* __restrict__ T = reinterpret_cast<half_t*>(g.C);
+    const int tile_n = id % g.tiles_n, tile_m = id / g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int z = blockIdx.z;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(g.A + (size_t)z * g.strideA), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(g.W + (size_t)z * g.strideW), 0, w_bytes, 0x00020000);
+
+    const int rsub = lane >> 3;            // row inside the 8-row group
+    const int ck = (lane & 7) ^ rsub;      // source chunk for this lane's LDS slot (swizzle)
+    unsigned a_voff[AR], b_voff[BR];       // byte offsets; >= *_bytes means "reads zero"
+    int a_off[AR], a_y[AR], a_x[AR];
+    bool a_ok[AR];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int n = n0 + wn * WTN + j * 16 + fr;
-                const int mb = m0 + wm * WTM + i * 16 + fq * 4;
-                if (n >= g.N) continue;
-                const float bn = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = mb + r;
-                    if (m >= g.M) continue;
-                    const int b = m / g.rows_per_batch, ml = m - b * g.rows_per_batch;
-                    const float v = act_apply(acc[i][j][r] * g.alpha + bn, g.act);
-                    T[(size_t)z * g.strideC + (size_t)b * g.strideT + (size_t)n * g.ldt + ml] =
-                        (half_t)v;
-                }
-            }
-        return;
-    }
-    const bool geglu = g.act == FD_ACT_GEGLU;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + fr;
-        if (m >= g.M) continue;
-        const int b = m / g.rows_per_batch;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int nb0 = n0 + wn * WTN + j * 16 + fq * 4;
-            if (nb0 >= g.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
-            if (g.bias) {
-                const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb0);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-            }
-            if (g.bias2) {
-                const float4 bb =
-                    *reinterpret_cast<const float4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-            }
-            if (geglu) {
-                // interleaved rows: even fragment = value, odd fragment = gate
-                if (j & 1) continue;
-                float gt[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gt[r] = acc[i][j + 1 < NI ? j + 1 : j][r] * g.alpha;
-                if (g.bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb0 + 16);
-                    gt[0] += bb.x; gt[1] += bb.y; gt[2] += bb.z; gt[3] += bb.w;
-                }
-                const int no = ((n0 + wn * WTN + j * 16) >> 1) + fq * 4;
-                half4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[r] * act_apply(gt[r], FD_ACT_GELU));
-                *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC +
-                                          (size_t)m * g.ldc + no) = o;
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], g.act);
-            if (g.res) {
-                const half4 rr = *reinterpret_cast<const half4*>(
-                    g.res + (size_t)z * g.strideRes + (size_t)m * g.ldr + nb0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-            }
-            if (g.out_f32) {
-                float* C = reinterpret_cast<float*>(g.C) + (size_t)z * g.strideC +
-                           (size_t)m * g.ldc + nb0;
-                if (nb0 + 3 < g.N) {
-                    *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    for (int r = 0; r < 4 && nb0 + r < g.N; ++r) C[r] = v[r];
-                }
-            } else {
-                half_t* C = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC +
-                            (size_t)m * g.ldc + nb0;
-                if (nb0 + 3 < g.N) {
-                    half4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-                    *reinterpret_cast<half4*>(C) = o;
-                } else {
-                    for (int r = 0; r < 4 && nb0 + r < g.N; ++r) C[r] = (half_t)v[r];
-                }
-            }
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + (i * 4 + wave) * 8 + rsub;
+        a_ok[i] = m < g.M;
+        const int mm = a_ok[i] ? m : 0;
+        if (CONV) {
+            const int hw = g.Ho * g.Wo;
+            const int b = mm / hw, rem = mm - b * hw;
+            const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+            a_off[i] = b * g.Hi * g.Wi * g.Cin + ck * 8;
+            a_y[i] = oy * g.stride - g.pad_t;
+            a_x[i] = ox * g.stride - g.pad_l;
+            a_voff[i] = a_bytes;
+        } else {
+            a_off[i] = a_y[i] = a_x[i] = 0;
+            a_voff[i] = a_ok[i] ? (unsigned)(mm * g.lda + ck * 8) * 2u : a_bytes;
         }
     }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + (i * 4 + wave) * 8 + rsub;
+        b_voff[i] = n < g.N ? (unsigned)(n * g.ldw + ck * 8) * 2u : w_bytes;
+    }
+    const int Hv = g.up ? g.Hi * 2 : g.Hi, Wv = g.up ? g.Wi * 2 : g.Wi;
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int kt_per = (nk_all + g.split_k - 1) / g.split_k;
+    const int kt0 = blockIdx.y * kt_per;
+    const int nk = min(nk_all, kt0 + kt_per);
+    const int ktail = g.K - ck * 8;
+    int kh = 0, kw = 0, ci0 = 0;
+    bool new_tap = true;
+    if (CONV && kt0 > 0) {
+        const int tap = (kt0 * BK) / g.Cin;
+        ci0 = kt0 * BK - tap * g.Cin;
+        kh = tap / g.KW;
+        kw = tap - kh * g.KW;
+    }
+
+#define GEMM_DMA_TILE(KT, BUF)                                                              \
+    {                                                                                       \
+        char* stage = smem + (BUF) * STAGE;                                                 \
+        if (CONV) {                                                                         \
+            if (new_tap) {                                                                  \
+                _Pragma("unroll") for (int i = 0; i < AR; ++i) {                            \
+                    int iy = a_y[i] + kh, ix = a_x[i] + kw;                                 \
+                    const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hv &&               \
+                                    (unsigned)ix < (unsigned)Wv;                            \
+                    if (g.up) {                                                             \
+                        iy >>= 1;                                                           \
+                        ix >>= 1;                                                           \
+                    }                                                                       \
+                    a_voff[i] = ok ? (unsigned)(a_off[i] + (iy * g.Wi + ix) * g.Cin) * 2u   \
+                                   : a_bytes;                                               \
+                }                                                                           \
+                new_tap = false;                                                            \
+            }                                                                               \
+            const int soff = ci0 * 2;                                                       \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i)                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
+                    rsA, (lds_ptr)(stage + (i * 4 + wave) * 1024), 16, a_voff[i], soff, 0, 0); \
+            ci0 += BK;                                                                      \
+            if (ci0 >= g.Cin) {                                                             \
+                ci0 = 0;                                                                    \
+                new_tap = true;                                                             \
+                if (++kw == g.KW) {                                                         \
+                    kw = 0;                                                                 \
+                    ++kh;                                                                   \
+                }                                                                           \
+            }                                                                               \
+        } else {                                                                            \
+            const bool kok = (KT) * BK < ktail;                                             \
+            const int soff = (KT) * BK * 2;                                                 \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i)                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
+                    rsA, (lds_ptr)(stage + (i * 4 + wave) * 1024), 16,                      \
+                    kok ? a_voff[i] : a_bytes, kok ? soff : 0, 0, 0);                       \
+        }                                                                                   \
+        {                                                                                   \
+            const bool kok = (KT) * BK < ktail;                                             \
+            const int soff = (KT) * BK * 2;                                                 \
+            _Pragma("unroll") for (int i = 0; i < BR; ++i)                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
+                    rsW, (lds_ptr)(stage + BM * 128 + (i * 4 + wave) * 1024), 16,           \
+                    kok ? b_voff[i] : w_bytes, kok ? soff : 0, 0, 0);                       \
+        }                                                                                   \
+    }
+
+    floatx4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    GEMM_DMA_TILE(kt0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int frag_a = (wm * WTM + fr) * 128, frag_b = BM * 128 + (wn * WTN + fr) * 128;
+    const int sw0 = ((0 * 4 + fq) ^ (fr & 7)) << 4, sw1 = ((1 * 4 + fq) ^ (fr & 7)) << 4;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        if (kt + 1 < nk) GEMM_DMA_TILE(kt + 1, cur ^ 1);
+        const char* st = smem + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int sw = ks ? sw1 : sw0;
+            half8 fa[MI], fb[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                fa[i] = *reinterpret_cast<const half8*>(st + frag_a + i * 2048 + sw);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                fb[j] = *reinterpret_cast<const half8*>(st + frag_b + j * 2048 + sw);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0,
+                                                                       0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef GEMM_DMA_TILE
+    gemm_epilogue<BM, BN, false>(g, acc, m0, n0, wm, wn, fr, fq, z);
+#endif
 }
 
 // Sums the split-K partial slabs in a fixed order and applies the fused epilogue.
@@ -391,18 +572,37 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs g) {
 }
 
 // --------------------------------------------------------------------------------------
+static bool g_use_dma = getenv("FD_GEMM_NO_DMA") == nullptr;
+
 template <int BM, int BN, bool TRANS, bool CONV>
 static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     g.tiles_m = fd_cdiv(g.M, BM);
     g.tiles_n = fd_cdiv(g.N, BN);
     const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    dim3 grid(g.tiles_m * g.tiles_n, g.split_k, batch);
+    // tensor extents for the buffer descriptors of the LDS-DMA loop (must fit 32 bits)
+    const unsigned long long a_bytes =
+        CONV ? 2ull * (g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi * g.Cin
+             : 2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K);
+    const unsigned long long w_bytes = 2ull * ((unsigned long long)(g.N - 1) * g.ldw + g.K);
+    if (!TRANS && g_use_dma && a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull) {
+        static bool configured = false;
+        if (!configured && lds > 64 * 1024) {
+            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured = true;
+        }
+        hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV>), grid, dim3(256), lds, st, g,
+                           (unsigned)a_bytes, (unsigned)w_bytes);
+        FD_CHECK_LAUNCH("k_gemm_f16_dma");
+        return FD_OK;
+    }
     static bool configured = false;
     if (!configured && lds > 64 * 1024) {
         FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16<BM, BN, TRANS, CONV>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    dim3 grid(g.tiles_m * g.tiles_n, g.split_k, batch);
     hipLaunchKernelGGL((k_gemm_f16<BM, BN, TRANS, CONV>), grid, dim3(256), lds, st, g);
     FD_CHECK_LAUNCH("k_gemm_f16");
     return FD_OK;

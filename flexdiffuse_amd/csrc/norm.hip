@@ -29,7 +29,25 @@ __global__ void k_gn_stats(const half_t* __restrict__ x, float* __restrict__ par
     for (int k = 0; k < 8; ++k) s[k] = q[k] = 0.f;
     if (pl < PL) {
         const half_t* base = x + ((size_t)b * HW) * C + cc * 8;
-        for (int p = p0 + pl; p < p1; p += PL) {
+        int p = p0 + pl;
+        // 4 independent 16-byte loads in flight per lane (the kernel is latency-bound otherwise)
+        for (; p + 3 * PL < p1; p += 4 * PL) {
+            uint4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                raw[u] = *reinterpret_cast<const uint4*>(base + (size_t)(p + u * PL) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const half8 v = *reinterpret_cast<const half8*>(&raw[u]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float f = (float)v[k];
+                    s[k] += f;
+                    q[k] = fmaf(f, f, q[k]);
+                }
+            }
+        }
+        for (; p < p1; p += PL) {
             const uint4 raw = *reinterpret_cast<const uint4*>(base + (size_t)p * C);
             const half8 v = *reinterpret_cast<const half8*>(&raw);
 #pragma unroll
@@ -101,7 +119,28 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ x,
     const int p1 = min(HW, p0 + pix_per_chunk);
     const size_t base = ((size_t)b * HW + p0) * C;
     const int total = (p1 - p0) * c8;
-    for (int e = tid; e < total; e += 256) {
+    int e = tid;
+    for (; e + 768 < total; e += 1024) {   // 4 independent vectors in flight per lane
+        uint4 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            raw[u] = *reinterpret_cast<const uint4*>(x + base + (size_t)(e + 256 * u) * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c0 = ((e + 256 * u) % c8) * 8;
+            const half8 v = *reinterpret_cast<const half8*>(&raw[u]);
+            half8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float f = fmaf((float)v[k], sc[c0 + k], sh[c0 + k]);
+                if (silu) f = f / (1.0f + __expf(-f));
+                o[k] = (half_t)f;
+            }
+            *reinterpret_cast<uint4*>(y + base + (size_t)(e + 256 * u) * 8) =
+                *reinterpret_cast<uint4*>(&o);
+        }
+    }
+    for (; e < total; e += 256) {
         const int c0 = (e % c8) * 8;
         const uint4 raw = *reinterpret_cast<const uint4*>(x + base + (size_t)e * 8);
         const half8 v = *reinterpret_cast<const half8*>(&raw);
@@ -134,7 +173,7 @@ extern "C" int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma,
     if (PL < 1) PL = 1;
     if (PL > HW) PL = HW;
     const int threads = ((c8 * PL + 63) / 64) * 64;
-    int nchunk = 2048 / B;
+    int nchunk = 1024 / B;
     if (nchunk < 1) nchunk = 1;
     if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
     int ppc = fd_cdiv(HW, nchunk);
