@@ -530,6 +530,199 @@ __global__ __launch_bounds__(256) void k_gemm_f16_dma(GemmArgs g, unsigned a_byt
 #endif
 }
 
+// Persistent variant of the LDS-DMA loop (used for short K loops).
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256, 2) void k_gemm_f16_dmap(GemmArgs g, unsigned a_bytes, unsigned w_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)  // body uses device-only builtins (host pass sees a stub)
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    constexpr int AR = BM / 32, BR = BN / 32;   // DMA instructions per wave per tile
+    constexpr int STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nb = g.tiles_m * g.tiles_n;
+    const int z = blockIdx.z;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(g.A + (size_t)z * g.strideA), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(g.W + (size_t)z * g.strideW), 0, w_bytes, 0x00020000);
+
+    const int rsub = lane >> 3;            // row inside the 8-row group
+    const int ck = (lane & 7) ^ rsub;      // source chunk for this lane's LDS slot (swizzle)
+    const int Hv = g.up ? g.Hi * 2 : g.Hi, Wv = g.up ? g.Wi * 2 : g.Wi;
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int kt_per = (nk_all + g.split_k - 1) / g.split_k;
+    const int kt0 = blockIdx.y * kt_per;
+    const int nk = min(nk_all, kt0 + kt_per);
+    const int ktail = g.K - ck * 8;
+
+    // ---- loader state of the tile whose K-tiles are being fetched -----------------------
+    unsigned a_voff[AR], b_voff[BR];       // byte offsets; >= *_bytes means "reads zero"
+    int a_off[AR], a_y[AR], a_x[AR];
+    bool a_ok[AR];
+    int kh = 0, kw = 0, ci0 = 0;
+    bool new_tap = true;
+    int ld_m0 = 0, ld_n0 = 0;
+
+    // XCD-aware tile order: every tile of this workgroup lives on its own XCD's chunk
+#define GEMM_SETUP_TILE(T)                                                                  \
+    {                                                                                       \
+        int id_ = (T);                                                                      \
+        {                                                                                   \
+            const int q = nb >> 3, r = nb & 7, xcd = id_ & 7, slot = id_ >> 3;              \
+            id_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;           \
+        }                                                                                   \
+        const int tile_n = id_ % g.tiles_n, tile_m = id_ / g.tiles_n;                       \
+        ld_m0 = tile_m * BM;                                                                \
+        ld_n0 = tile_n * BN;                                                                \
+        _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                    \
+            const int m = ld_m0 + (i * 4 + wave) * 8 + rsub;                                \
+            a_ok[i] = m < g.M;                                                              \
+            const int mm = a_ok[i] ? m : 0;                                                 \
+            if (CONV) {                                                                     \
+                const int hw = g.Ho * g.Wo;                                                 \
+                const int b = mm / hw, rem = mm - b * hw;                                   \
+                const int oy = rem / g.Wo, ox = rem - oy * g.Wo;                            \
+                a_off[i] = b * g.Hi * g.Wi * g.Cin + ck * 8;                                \
+                a_y[i] = oy * g.stride - g.pad_t;                                           \
+                a_x[i] = ox * g.stride - g.pad_l;                                           \
+                a_voff[i] = a_bytes;                                                        \
+            } else {                                                                        \
+                a_off[i] = a_y[i] = a_x[i] = 0;                                             \
+                a_voff[i] = a_ok[i] ? (unsigned)(mm * g.lda + ck * 8) * 2u : a_bytes;       \
+            }                                                                               \
+        }                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                    \
+            const int n = ld_n0 + (i * 4 + wave) * 8 + rsub;                                \
+            b_voff[i] = n < g.N ? (unsigned)(n * g.ldw + ck * 8) * 2u : w_bytes;            \
+        }                                                                                   \
+        kh = kw = ci0 = 0;                                                                  \
+        new_tap = true;                                                                     \
+        if (CONV && kt0 > 0) {                                                              \
+            const int tap = (kt0 * BK) / g.Cin;                                             \
+            ci0 = kt0 * BK - tap * g.Cin;                                                   \
+            kh = tap / g.KW;                                                                \
+            kw = tap - kh * g.KW;                                                           \
+        }                                                                                   \
+    }
+
+#define GEMM_DMA_TILE(KT, BUF)                                                              \
+    {                                                                                       \
+        char* stage_ = smem + (BUF) * STAGE;                                                \
+        if (CONV) {                                                                         \
+            if (new_tap) {                                                                  \
+                _Pragma("unroll") for (int i = 0; i < AR; ++i) {                            \
+                    int iy = a_y[i] + kh, ix = a_x[i] + kw;                                 \
+                    const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hv &&               \
+                                    (unsigned)ix < (unsigned)Wv;                            \
+                    if (g.up) {                                                             \
+                        iy >>= 1;                                                           \
+                        ix >>= 1;                                                           \
+                    }                                                                       \
+                    a_voff[i] = ok ? (unsigned)(a_off[i] + (iy * g.Wi + ix) * g.Cin) * 2u   \
+                                   : a_bytes;                                               \
+                }                                                                           \
+                new_tap = false;                                                            \
+            }                                                                               \
+            const int soff = ci0 * 2;                                                       \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i)                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
+                    rsA, (lds_ptr)(stage_ + (i * 4 + wave) * 1024), 16, a_voff[i], soff, 0, 0); \
+            ci0 += BK;                                                                      \
+            if (ci0 >= g.Cin) {                                                             \
+                ci0 = 0;                                                                    \
+                new_tap = true;                                                             \
+                if (++kw == g.KW) {                                                         \
+                    kw = 0;                                                                 \
+                    ++kh;                                                                   \
+                }                                                                           \
+            }                                                                               \
+        } else {                                                                            \
+            const bool kok = (KT) * BK < ktail;                                             \
+            const int soff = (KT) * BK * 2;                                                 \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i)                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
+                    rsA, (lds_ptr)(stage_ + (i * 4 + wave) * 1024), 16,                     \
+                    kok ? a_voff[i] : a_bytes, kok ? soff : 0, 0, 0);                       \
+        }                                                                                   \
+        {                                                                                   \
+            const bool kok = (KT) * BK < ktail;                                             \
+            const int soff = (KT) * BK * 2;                                                 \
+            _Pragma("unroll") for (int i = 0; i < BR; ++i)                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
+                    rsW, (lds_ptr)(stage_ + BM * 128 + (i * 4 + wave) * 1024), 16,          \
+                    kok ? b_voff[i] : w_bytes, kok ? soff : 0, 0, 0);                       \
+        }                                                                                   \
+    }
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int frag_a = (wm * WTM + fr) * 128, frag_b = BM * 128 + (wn * WTN + fr) * 128;
+    const int sw0 = ((0 * 4 + fq) ^ (fr & 7)) << 4, sw1 = ((1 * 4 + fq) ^ (fr & 7)) << 4;
+
+    // ---- persistent loop over this workgroup's tiles: the first K-tile of the NEXT output
+    // tile is already in flight while the current tile's epilogue runs, so short-K GEMMs do
+    // not expose the HBM/L2 latency of a fresh prologue for every tile ----------------------
+    int t = blockIdx.x;
+    int stage = 0;
+    GEMM_SETUP_TILE(t);
+    GEMM_DMA_TILE(kt0, 0);
+    floatx4 acc[MI][NI];
+#pragma clang loop unroll(disable)
+    while (t < nb) {
+        const int m0 = ld_m0, n0 = ld_n0;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int t_next = t + gridDim.x;
+#pragma clang loop unroll(disable)
+        for (int kt = kt0; kt < nk; ++kt) {
+            const int cur = stage;
+            const bool last = kt + 1 >= nk;
+            if (!last) {
+                GEMM_DMA_TILE(kt + 1, cur ^ 1);
+            } else if (t_next < nb) {
+                GEMM_SETUP_TILE(t_next);
+                GEMM_DMA_TILE(kt0, cur ^ 1);
+            }
+            const char* st = smem + cur * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int sw = ks ? sw1 : sw0;
+                half8 fa[MI], fb[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    fa[i] = *reinterpret_cast<const half8*>(st + frag_a + i * 2048 + sw);
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    fb[j] = *reinterpret_cast<const half8*>(st + frag_b + j * 2048 + sw);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j],
+                                                                           0, 0, 0);
+            }
+            stage ^= 1;
+            if (!last) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+        gemm_epilogue<BM, BN, false>(g, acc, m0, n0, wm, wn, fr, fq, z);
+        t = t_next;
+    }
+#undef GEMM_DMA_TILE
+#undef GEMM_SETUP_TILE
+#endif
+}
+
 // Sums the split-K partial slabs in a fixed order and applies the fused epilogue.
 __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs g) {
     const int n4 = g.N >> 2;
@@ -573,6 +766,8 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs g) {
 
 // --------------------------------------------------------------------------------------
 static bool g_use_dma = getenv("FD_GEMM_NO_DMA") == nullptr;
+// 0 = never, 1 = short-K GEMMs only (default), 2 = always
+static int g_persist_mode = getenv("FD_GEMM_PERSIST") ? atoi(getenv("FD_GEMM_PERSIST")) : 1;
 
 template <int BM, int BN, bool TRANS, bool CONV>
 static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
@@ -590,10 +785,25 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         if (!configured && lds > 64 * 1024) {
             FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dmap<BM, BN, CONV>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
-        hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV>), grid, dim3(256), lds, st, g,
-                           (unsigned)a_bytes, (unsigned)w_bytes);
+        // Short K loops: persistent workgroups (<= 256 CUs x co-resident workgroups) walk the
+        // tile list with the next tile's first K-tile prefetched under the epilogue.
+        const int occ = (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);
+        const int slots = 256 * occ;
+        const int nkt = (g.K + BK - 1) / BK / g.split_k;
+        const bool persistent = g_persist_mode == 2 ||
+                                (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots);
+        if (persistent) {
+            dim3 pgrid(g.tiles_m * g.tiles_n > slots ? slots : g.tiles_m * g.tiles_n, g.split_k, batch);
+            hipLaunchKernelGGL((k_gemm_f16_dmap<BM, BN, CONV>), pgrid, dim3(256), lds, st, g,
+                               (unsigned)a_bytes, (unsigned)w_bytes);
+        } else {
+            hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV>), grid, dim3(256), lds, st, g,
+                               (unsigned)a_bytes, (unsigned)w_bytes);
+        }
         FD_CHECK_LAUNCH("k_gemm_f16_dma");
         return FD_OK;
     }
