@@ -68,6 +68,32 @@ def cpu_baseline(sds, cfgs, steps):
                       f'({os.cpu_count()} cpus); extrapolated to {steps} steps + decode per image'}
 
 
+def parity_leg(sds, cfgs, pipe, enc, tok, steps=10, hw=256, guidance=8.0):
+    '''BASELINE configs[0] shape (256x256, 10 DDIM steps, batch 1, CFG 8) on the same SD1.5
+    weights: GPU fp16 path vs the CPU fp32 oracle with identical ids and CPU-drawn noise.'''
+    from flexdiffuse_amd import SimpleGuide
+    from oracle import clip_ref, pipeline_ref
+    ucfg, vcfg, ccfg = cfgs
+    prompt = 'a photo of a turtle in a forest, oil painting'
+    emb_dev = enc.prompt(prompt)
+    pipe(guide=SimpleGuide(enc, pipe.unet, guidance, steps, emb_dev), init_size=(hw, hw),
+         generator=torch.Generator('cpu').manual_seed(1337), output_type='np')
+    text_sd = {k: v for k, v in sds['clip'].items() if k.startswith('text_model')}
+    emb_ref = clip_ref.text_hidden(text_sd, ccfg, tok(prompt).input_ids)
+    unc_ref = clip_ref.text_hidden(text_sd, ccfg, tok('').input_ids)
+    lat0 = torch.randn((1, 4, hw // 8, hw // 8), generator=torch.Generator('cpu').manual_seed(1337))
+    t0 = time.time()
+    lat_ref, used = pipeline_ref.denoise(sds['unet'], ucfg, emb_ref, unc_ref, lat0, steps, guidance)
+    img_ref = pipeline_ref.decode_image(sds['vae'], vcfg, lat_ref)
+    cpu_s = time.time() - t0
+    lat = pipe.last_latents.float().cpu()
+    return {'config': f'SD1.5 {hw}x{hw}, {steps} DDIM steps, batch 1, CFG {guidance} (BASELINE configs[0])',
+            'psnr_db': pipeline_ref.psnr(pipe.last_images.cpu(), img_ref),
+            'latent_max_abs_err': float((lat - lat_ref).abs().max()),
+            'timesteps_equal': used == [int(t) for t in pipe.scheduler.timesteps],
+            'cpu_oracle_seconds': cpu_s, 'tolerance': 'PSNR >= 40 dB'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -78,6 +104,7 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--preset', default='sd15')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -186,6 +213,8 @@ def main():
         if N == 1 and not args.no_cpu_baseline:
             sds32 = sds if args.preset != 'sd15' else sds
             line['cpu_baseline'] = cpu_baseline(sds32, cfgs, args.ddim_steps)
+        if N == 1 and not args.no_parity and args.preset == 'sd15':
+            line['parity'] = parity_leg(sds, cfgs, pipe, enc, tok)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -193,3 +193,36 @@ def test_pipeline_errors_and_outputs(mini, dev):
     imgs, flag = pipe(guide=guide, init_size=(64, 64), return_dict=False, debug=True,
                       generator=torch.Generator('cpu').manual_seed(3))
     assert flag is False and len(imgs) == 3     # initial + 2 steps
+
+
+def test_sd15_c1_pipeline_psnr(dev):
+    '''BASELINE configs[0] shape on the full SD1.5 architecture (859,520,964-parameter UNet,
+    83.6 M VAE, CLIP ViT-L/14 text tower): 256x256, 10 DDIM steps, batch 1, CFG 8.
+    GPU fp16 path vs CPU fp32 oracle on identical seeded weights, ids and CPU-drawn noise:
+    integer timestep lists equal, final-image PSNR >= 40 dB, latent error reported.'''
+    from flexdiffuse_amd import SimpleGuide, build
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from oracle import clip_ref, pipeline_ref
+    sds = build.synthetic_state_dicts('sd15', seed=0)
+    ucfg, vcfg, ccfg = build.configs('sd15')
+    pipe, clip, tok = build.build_models(sds, 'sd15', dev, vae_encoder=False)
+    enc = CLIPEncoder(clip, tok)
+    prompt = 'a photo of a turtle in a forest, oil painting'
+    steps, guidance, hw = 10, 8.0, 256
+    emb_dev = enc.prompt(prompt)
+    out = pipe(guide=SimpleGuide(enc, pipe.unet, guidance, steps, emb_dev), init_size=(hw, hw),
+               generator=torch.Generator('cpu').manual_seed(1337), output_type='np')
+    text_sd = {k: v for k, v in sds['clip'].items() if k.startswith('text_model')}
+    emb_ref = clip_ref.text_hidden(text_sd, ccfg, tok(prompt).input_ids)
+    unc_ref = clip_ref.text_hidden(text_sd, ccfg, tok('').input_ids)
+    assert relerr(emb_dev, emb_ref) < 2e-2
+    lat0 = torch.randn((1, 4, hw // 8, hw // 8), generator=torch.Generator('cpu').manual_seed(1337))
+    lat_ref, used = pipeline_ref.denoise(sds['unet'], ucfg, emb_ref, unc_ref, lat0, steps, guidance)
+    img_ref = pipeline_ref.decode_image(sds['vae'], vcfg, lat_ref)
+    assert used == [int(t) for t in pipe.scheduler.timesteps]
+    p = pipeline_ref.psnr(pipe.last_images.cpu(), img_ref)
+    print(f'SD1.5 c1: latent rel err {relerr(pipe.last_latents, lat_ref):.4f}, PSNR {p:.1f} dB, '
+          f'image std {float(img_ref.std()):.3f}')
+    assert out.images.shape == (1, hw, hw, 3)
+    assert float(img_ref.std()) > 0.02, 'degenerate image: parity would be vacuous'
+    assert p >= 40.0, p
