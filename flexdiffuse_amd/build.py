@@ -13,8 +13,15 @@ from .tokenizer import SyntheticTokenizer
 from .unet import UNet2DConditionModel
 from .vae import AutoencoderKL
 
+import dataclasses
+
+# SD2.x-style small model: linear proj_in/out, head dim 64, v-prediction (BASELINE config 5 shape)
+MINI2_UNET = dataclasses.replace(W.MINI_UNET, num_heads=(5, 10, 20), use_linear_projection=True,
+                                 prediction_type='v_prediction')
+
 PRESETS = {
     'sd15': (W.SD15_UNET, W.SD_VAE, W.CLIP_VIT_L14),
+    'mini2': (MINI2_UNET, W.MINI_VAE, W.MINI_CLIP),
     'sd21': (W.SD21_UNET, W.SD_VAE, W.CLIP_VIT_H14),
     'mini': (W.MINI_UNET, W.MINI_VAE, W.MINI_CLIP),
 }
@@ -29,8 +36,8 @@ def synthetic_state_dicts(preset: str = 'sd15', seed: int = 0, branch_gain: floa
                           parts=('unet', 'vae', 'clip')) -> Dict[str, dict]:
     '''Seeded fp32 CPU state dicts (HF key names) of the named architecture.'''
     ucfg, vcfg, ccfg = PRESETS[preset]
-    if preset == 'mini':
-        ucfg = mini_unet_config(ccfg)
+    if preset.startswith('mini'):
+        ucfg = dataclasses.replace(ucfg, cross_attention_dim=ccfg.text.hidden_size)
     out = {}
     if 'unet' in parts:
         out['unet'] = W.synth_state_dict(W.unet_param_shapes(ucfg), seed, branch_gain, 'unet.')
@@ -43,8 +50,8 @@ def synthetic_state_dicts(preset: str = 'sd15', seed: int = 0, branch_gain: floa
 
 def configs(preset: str):
     ucfg, vcfg, ccfg = PRESETS[preset]
-    if preset == 'mini':
-        ucfg = mini_unet_config(ccfg)
+    if preset.startswith('mini'):
+        ucfg = dataclasses.replace(ucfg, cross_attention_dim=ccfg.text.hidden_size)
     return ucfg, vcfg, ccfg
 
 

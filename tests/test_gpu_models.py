@@ -226,3 +226,88 @@ def test_sd15_c1_pipeline_psnr(dev):
     assert out.images.shape == (1, hw, hw, 3)
     assert float(img_ref.std()) > 0.02, 'degenerate image: parity would be vacuous'
     assert p >= 40.0, p
+
+
+def test_img2img_vs_oracle(mini, dev):
+    '''img2img branch (pipeline/flex.py:181-221): VAE encode -> posterior sample -> x0.18215 ->
+    add_noise at timesteps[-init_timestep] -> loop from t_start.  strength 0.6 / 10 steps.'''
+    from flexdiffuse_amd import SimpleGuide
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from oracle import clip_ref, pipeline_ref
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = mini
+    enc = CLIPEncoder(clip, tok)
+    steps, strength, guidance, B = 10, 0.6, 8.0, 2
+    prompts = ['a photo of a turtle', 'zeus, oil painting']
+    g = torch.Generator().manual_seed(5)
+    image = (torch.rand((1, 3, 32, 32), generator=g) * 2 - 1).half().float()
+    emb_dev = enc.prompt(prompts)
+    out = pipe(guide=SimpleGuide(enc, pipe.unet, guidance, steps, emb_dev), init_image=image,
+               strength=strength, generator=torch.Generator('cpu').manual_seed(11),
+               output_type='np')
+    # the same two draws from the same CPU generator stream: posterior noise, then latent noise
+    gen = torch.Generator('cpu').manual_seed(11)
+    post = torch.randn((1, 4, 16, 16), generator=gen)
+    noise = torch.randn((B, 4, 16, 16), generator=gen)
+    lat0, t_start = pipeline_ref.img2img_init(sds['vae'], vcfg, image, post, noise, steps, strength, B)
+    assert t_start == 4
+    ids = tok(prompts).input_ids
+    emb_ref = clip_ref.text_hidden(sds['clip'], ccfg, ids)
+    unc_ref = clip_ref.text_hidden(sds['clip'], ccfg, tok('').input_ids)
+    lat_ref, used = pipeline_ref.denoise(sds['unet'], ucfg, emb_ref, unc_ref, lat0, steps, guidance,
+                                         t_start=t_start)
+    assert used == [500, 400, 300, 200, 100, 0]
+    img_ref = pipeline_ref.decode_image(sds['vae'], vcfg, lat_ref)
+    p = pipeline_ref.psnr(pipe.last_images.cpu(), img_ref)
+    print(f'img2img: latent rel err {relerr(pipe.last_latents, lat_ref):.4f}, PSNR {p:.1f} dB')
+    assert p >= 40.0, p
+
+
+def test_sd2_style_unet_vprediction(dev):
+    '''SD2.x-shaped small model (linear proj_in/out, head dim 64, v-prediction; BASELINE
+    config 5's differences from SD1.x) vs the CPU oracle, single forward + 4-step loop.'''
+    from flexdiffuse_amd import SimpleGuide, build
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from oracle import clip_ref, pipeline_ref, unet_ref
+    sds = build.synthetic_state_dicts('mini2', seed=1)
+    sds = {k: {n: t.half().float() for n, t in sd.items()} for k, sd in sds.items()}
+    pipe, clip, tok = build.build_models(sds, 'mini2', dev)
+    ucfg, vcfg, ccfg = build.configs('mini2')
+    assert ucfg.use_linear_projection and ucfg.prediction_type == 'v_prediction'
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((2, 4, 16, 16), generator=g)
+    ctx = torch.randn((2, 77, ucfg.cross_attention_dim), generator=g).half().float()
+    want = unet_ref.unet_forward(sds['unet'], ucfg, x, 500, ctx)
+    got = pipe.unet(x.to(dev), 500, encoder_hidden_states=ctx.to(dev)).sample
+    assert relerr(got, want) < 3e-2
+    enc = CLIPEncoder(clip, tok)
+    emb_dev = enc.prompt('a cat')
+    pipe(guide=SimpleGuide(enc, pipe.unet, 8.0, 4, emb_dev), init_size=(64, 64),
+         generator=torch.Generator('cpu').manual_seed(2), output_type='np')
+    emb_ref = clip_ref.text_hidden(sds['clip'], ccfg, tok('a cat').input_ids)
+    unc_ref = clip_ref.text_hidden(sds['clip'], ccfg, tok('').input_ids)
+    lat0 = torch.randn((1, 4, 8, 8), generator=torch.Generator('cpu').manual_seed(2))
+    lat_ref, _ = pipeline_ref.denoise(sds['unet'], ucfg, emb_ref, unc_ref, lat0, 4, 8.0)
+    img_ref = pipeline_ref.decode_image(sds['vae'], vcfg, lat_ref)
+    p = pipeline_ref.psnr(pipe.last_images.cpu(), img_ref)
+    print(f'sd2-style: PSNR {p:.1f} dB')
+    assert p >= 40.0, p
+
+
+def test_runner_gen_recipe(dev):
+    '''utils.Runner.gen call recipe: seed -> Guide.embeds -> SimpleGuide -> sequential batches;
+    the same seed reproduces the same images, a different seed does not.'''
+    from flexdiffuse_amd import Runner
+    from test_oracle_clip import synth_image
+    r = Runner(preset='mini', device='cuda')
+    img = synth_image(20, 512, 512)
+    imgs, grid = r.gen(prompt='a photo of a turtle', guide=img, init_size=(64, 64), steps=3,
+                       samples=2, seed=1337, guide_clustered=0.0)
+    assert len(imgs) == 2 and grid.size == (2 * imgs[0].size[0], imgs[0].size[1])
+    again, _ = r.gen(prompt='a photo of a turtle', guide=img, init_size=(64, 64), steps=3,
+                     samples=2, seed=1337, guide_clustered=0.0)
+    other, _ = r.gen(prompt='a photo of a turtle', guide=img, init_size=(64, 64), steps=3,
+                     samples=1, seed=7, guide_clustered=0.0)
+    assert np.array_equal(np.asarray(imgs[0]), np.asarray(again[0]))
+    assert np.array_equal(np.asarray(imgs[1]), np.asarray(again[1]))
+    assert not np.array_equal(np.asarray(imgs[0]), np.asarray(other[0]))
+    assert r._set_seed(-5) == 0 and r._set_seed(2 ** 40) == 2147483647
