@@ -140,10 +140,7 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
         const bool need_mask = (j * 64 + 64 > a.Nk) || a.causal;
         // ---- S^T tile: 64 keys x (QT x 16) queries ---------------------------------------
         floatx4 s[4][QT];
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int t = 0; t < QT; ++t) s[f][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const floatx4 zacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -152,7 +149,8 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
                                                                  (ks * 4 + g) * 16);
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
-                    s[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], s[f][t], 0, 0, 0);
+                    s[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks],
+                                                                     ks == 0 ? zacc : s[f][t], 0, 0, 0);
             }
         // ---- online softmax, all statistics lane-local (query = fr) -----------------------
         half8 p[2][QT];
@@ -178,23 +176,32 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
             // running max kept in raw-score units; p = 2^(s*c2 - m*c2) as one fma + v_exp_f32
             const float mnew = fmaxf(mrow[t], tmax);
             const bool dead = mnew == -INFINITY;
-            const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f((mrow[t] - mnew) * c2);
             const float mc = dead ? 0.f : mnew * c2;
-            mrow[t] = mnew;
-            float psum = 0.f;
+            const bool moved = mnew != mrow[t];
+            if (__any(moved)) {   // wave-uniform: rescale only when some row's running max grew
+                const float alpha = (dead || !moved) ? 1.f : __builtin_amdgcn_exp2f((mrow[t] - mnew) * c2);
+                lrow[t] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DV; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[t][dt][r] *= alpha;
+                mrow[t] = mnew;
+            }
+            // p = 2^(s*c2 - m*c2): packed fp32 fma / add (v_pk_fma_f32, v_pk_add_f32)
+            floatx2 ps = {0.f, 0.f};
+            const floatx2 c2v = {c2, c2}, mcv = {mc, mc};
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s[f][t][r], c2, -mc));
-                    psum += e;
-                    p[f >> 1][t][(f & 1) * 4 + r] = (half_t)e;
+                for (int r = 0; r < 4; r += 2) {
+                    floatx2 x = {s[f][t][r], s[f][t][r + 1]};
+                    x = x * c2v - mcv;
+                    floatx2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                    ps += e;
+                    p[f >> 1][t][(f & 1) * 4 + r] = (half_t)e[0];
+                    p[f >> 1][t][(f & 1) * 4 + r + 1] = (half_t)e[1];
                 }
-            lrow[t] = lrow[t] * alpha + psum;
-#pragma unroll
-            for (int dt = 0; dt < DV; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[t][dt][r] *= alpha;
+            lrow[t] += ps[0] + ps[1];
         }
         // ---- O^T += V^T P^T ------------------------------------------------------------------
 #pragma unroll

@@ -45,6 +45,7 @@ typedef _Float16 half_t;
 typedef half_t half8 __attribute__((ext_vector_type(8)));
 typedef half_t half4 __attribute__((ext_vector_type(4)));
 typedef half_t half2v __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
