@@ -78,11 +78,11 @@ __device__ __forceinline__ float act_apply(float x, int act) {
 }
 
 // Fused epilogue shared by the register-staged and the LDS-DMA main loops.
-template <int BM, int BN, bool TRANS>
+template <int BM, int BN, bool TRANS, int WM = 2>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
-                                              floatx4 (&acc)[BM / 32][BN / 32], int m0, int n0,
+                                              floatx4 (&acc)[BM / WM / 16][BN / 32], int m0, int n0,
                                               int wm, int wn, int fr, int fq, int z) {
-    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int WTM = BM / WM, WTN = BN / 2;
     constexpr int MI = WTM / 16, NI = WTN / 16;
     // ---- split-K: raw fp32 partial tile, reduced + finished by k_splitk_finish ------------
     if (g.split_k > 1) {
@@ -386,12 +386,14 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
 // by the buffer descriptor's bounds check (an offset past num_records reads 0), so there is
 // no select or branch on the load path.  The K-tile offset rides in the scalar soffset, so
 // per-lane address math only runs when the filter tap changes.
-template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(256) void k_gemm_f16_dma(GemmArgs g, unsigned a_bytes, unsigned w_bytes) {
+template <int BM, int BN, bool CONV, int WM>
+__global__ __launch_bounds__(128 * WM) void k_gemm_f16_dma(GemmArgs g, unsigned a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses device-only builtins (host pass sees a stub)
-    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int NW = 2 * WM;                  // waves: WM along M x 2 along N
+    constexpr int WTM = BM / WM, WTN = BN / 2;
     constexpr int MI = WTM / 16, NI = WTN / 16;
-    constexpr int AR = BM / 32, BR = BN / 32;   // DMA instructions per wave per tile
+    constexpr int AG = BM / 8, BG = BN / 8;     // 8-row DMA groups of the A / B tile
+    constexpr int AR = (AG + NW - 1) / NW, BR = (BG + NW - 1) / NW;  // DMA instr. per wave
     constexpr int STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16_dma(GemmArgs g, unsigned a_byt
     bool a_ok[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int m = m0 + (i * 4 + wave) * 8 + rsub;
+        const int m = m0 + (i * NW + wave) * 8 + rsub;
         a_ok[i] = m < g.M;
         const int mm = a_ok[i] ? m : 0;
         if (CONV) {
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16_dma(GemmArgs g, unsigned a_byt
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-        const int n = n0 + (i * 4 + wave) * 8 + rsub;
+        const int n = n0 + (i * NW + wave) * 8 + rsub;
         b_voff[i] = n < g.N ? (unsigned)(n * g.ldw + ck * 8) * 2u : w_bytes;
     }
     const int Hv = g.up ? g.Hi * 2 : g.Hi, Wv = g.up ? g.Wi * 2 : g.Wi;
@@ -476,8 +478,9 @@ __global__ __launch_bounds__(256) void k_gemm_f16_dma(GemmArgs g, unsigned a_byt
             }                                                                               \
             const int soff = ci0 * 2;                                                       \
             _Pragma("unroll") for (int i = 0; i < AR; ++i)                                  \
+                if (AG % NW == 0 || i * NW + wave < AG)                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
-                    rsA, (lds_ptr)(stage + (i * 4 + wave) * 1024), 16, a_voff[i], soff, 0, 0); \
+                    rsA, (lds_ptr)(stage + (i * NW + wave) * 1024), 16, a_voff[i], soff, 0, 0); \
             ci0 += BK;                                                                      \
             if (ci0 >= g.Cin) {                                                             \
                 ci0 = 0;                                                                    \
@@ -491,16 +494,18 @@ __global__ __launch_bounds__(256) void k_gemm_f16_dma(GemmArgs g, unsigned a_byt
             const bool kok = (KT) * BK < ktail;                                             \
             const int soff = (KT) * BK * 2;                                                 \
             _Pragma("unroll") for (int i = 0; i < AR; ++i)                                  \
+                if (AG % NW == 0 || i * NW + wave < AG)                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
-                    rsA, (lds_ptr)(stage + (i * 4 + wave) * 1024), 16,                      \
+                    rsA, (lds_ptr)(stage + (i * NW + wave) * 1024), 16,                      \
                     kok ? a_voff[i] : a_bytes, kok ? soff : 0, 0, 0);                       \
         }                                                                                   \
         {                                                                                   \
             const bool kok = (KT) * BK < ktail;                                             \
             const int soff = (KT) * BK * 2;                                                 \
             _Pragma("unroll") for (int i = 0; i < BR; ++i)                                  \
+                if (BG % NW == 0 || i * NW + wave < BG)                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
-                    rsW, (lds_ptr)(stage + BM * 128 + (i * 4 + wave) * 1024), 16,           \
+                    rsW, (lds_ptr)(stage + BM * 128 + (i * NW + wave) * 1024), 16,           \
                     kok ? b_voff[i] : w_bytes, kok ? soff : 0, 0, 0);                       \
         }                                                                                   \
     }
@@ -542,17 +547,19 @@ __global__ __launch_bounds__(256) void k_gemm_f16_dma(GemmArgs g, unsigned a_byt
         __syncthreads();
     }
 #undef GEMM_DMA_TILE
-    gemm_epilogue<BM, BN, false>(g, acc, m0, n0, wm, wn, fr, fq, z);
+    gemm_epilogue<BM, BN, false, WM>(g, acc, m0, n0, wm, wn, fr, fq, z);
 #endif
 }
 
 // Persistent variant of the LDS-DMA loop (used for short K loops).
-template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(256, 2) void k_gemm_f16_dmap(GemmArgs g, unsigned a_bytes, unsigned w_bytes) {
+template <int BM, int BN, bool CONV, int WM>
+__global__ __launch_bounds__(128 * WM, 2) void k_gemm_f16_dmap(GemmArgs g, unsigned a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses device-only builtins (host pass sees a stub)
-    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int NW = 2 * WM;                  // waves: WM along M x 2 along N
+    constexpr int WTM = BM / WM, WTN = BN / 2;
     constexpr int MI = WTM / 16, NI = WTN / 16;
-    constexpr int AR = BM / 32, BR = BN / 32;   // DMA instructions per wave per tile
+    constexpr int AG = BM / 8, BG = BN / 8;     // 8-row DMA groups of the A / B tile
+    constexpr int AR = (AG + NW - 1) / NW, BR = (BG + NW - 1) / NW;  // DMA instr. per wave
     constexpr int STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_dmap(GemmArgs g, unsigned a
         ld_m0 = tile_m * BM;                                                                \
         ld_n0 = tile_n * BN;                                                                \
         _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                    \
-            const int m = ld_m0 + (i * 4 + wave) * 8 + rsub;                                \
+            const int m = ld_m0 + (i * NW + wave) * 8 + rsub;                                \
             a_ok[i] = m < g.M;                                                              \
             const int mm = a_ok[i] ? m : 0;                                                 \
             if (CONV) {                                                                     \
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_dmap(GemmArgs g, unsigned a
             }                                                                               \
         }                                                                                   \
         _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                    \
-            const int n = ld_n0 + (i * 4 + wave) * 8 + rsub;                                \
+            const int n = ld_n0 + (i * NW + wave) * 8 + rsub;                                \
             b_voff[i] = n < g.N ? (unsigned)(n * g.ldw + ck * 8) * 2u : w_bytes;            \
         }                                                                                   \
         kh = kw = ci0 = 0;                                                                  \
@@ -646,8 +653,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_dmap(GemmArgs g, unsigned a
             }                                                                               \
             const int soff = ci0 * 2;                                                       \
             _Pragma("unroll") for (int i = 0; i < AR; ++i)                                  \
+                if (AG % NW == 0 || i * NW + wave < AG)                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
-                    rsA, (lds_ptr)(stage_ + (i * 4 + wave) * 1024), 16, a_voff[i], soff, 0, 0); \
+                    rsA, (lds_ptr)(stage_ + (i * NW + wave) * 1024), 16, a_voff[i], soff, 0, 0); \
             ci0 += BK;                                                                      \
             if (ci0 >= g.Cin) {                                                             \
                 ci0 = 0;                                                                    \
@@ -661,16 +669,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_dmap(GemmArgs g, unsigned a
             const bool kok = (KT) * BK < ktail;                                             \
             const int soff = (KT) * BK * 2;                                                 \
             _Pragma("unroll") for (int i = 0; i < AR; ++i)                                  \
+                if (AG % NW == 0 || i * NW + wave < AG)                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
-                    rsA, (lds_ptr)(stage_ + (i * 4 + wave) * 1024), 16,                     \
+                    rsA, (lds_ptr)(stage_ + (i * NW + wave) * 1024), 16,                     \
                     kok ? a_voff[i] : a_bytes, kok ? soff : 0, 0, 0);                       \
         }                                                                                   \
         {                                                                                   \
             const bool kok = (KT) * BK < ktail;                                             \
             const int soff = (KT) * BK * 2;                                                 \
             _Pragma("unroll") for (int i = 0; i < BR; ++i)                                  \
+                if (BG % NW == 0 || i * NW + wave < BG)                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
-                    rsW, (lds_ptr)(stage_ + BM * 128 + (i * 4 + wave) * 1024), 16,          \
+                    rsW, (lds_ptr)(stage_ + BM * 128 + (i * NW + wave) * 1024), 16,          \
                     kok ? b_voff[i] : w_bytes, kok ? soff : 0, 0, 0);                       \
         }                                                                                   \
     }
@@ -731,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_dmap(GemmArgs g, unsigned a
                 __syncthreads();
             }
         }
-        gemm_epilogue<BM, BN, false>(g, acc, m0, n0, wm, wn, fr, fq, z);
+        gemm_epilogue<BM, BN, false, WM>(g, acc, m0, n0, wm, wn, fr, fq, z);
         t = t_next;
     }
 #undef GEMM_DMA_TILE
@@ -785,7 +795,7 @@ static bool g_use_dma = getenv("FD_GEMM_NO_DMA") == nullptr;
 // 0 = never, 1 = short-K GEMMs only (default), 2 = always
 static int g_persist_mode = getenv("FD_GEMM_PERSIST") ? atoi(getenv("FD_GEMM_PERSIST")) : 1;
 
-template <int BM, int BN, bool TRANS, bool CONV>
+template <int BM, int BN, bool TRANS, bool CONV, int WM = 2>
 static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     g.tiles_m = fd_cdiv(g.M, BM);
     g.tiles_n = fd_cdiv(g.N, BN);
@@ -799,45 +809,50 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     if (!TRANS && g_use_dma && a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull) {
         static bool configured = false;
         if (!configured && lds > 64 * 1024) {
-            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV>),
+            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV, WM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dmap<BM, BN, CONV>),
+            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dmap<BM, BN, CONV, WM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
         // Short K loops: persistent workgroups (<= 256 CUs x co-resident workgroups) walk the
         // tile list with the next tile's first K-tile prefetched under the epilogue.
-        const int occ = (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);
+        const int occ = BM >= 256 ? 1 : (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);
         const int slots = 256 * occ;
         const int nkt = (g.K + BK - 1) / BK / g.split_k;
         const bool persistent = g_persist_mode == 2 ||
                                 (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots);
         if (persistent) {
             dim3 pgrid(g.tiles_m * g.tiles_n > slots ? slots : g.tiles_m * g.tiles_n, g.split_k, batch);
-            hipLaunchKernelGGL((k_gemm_f16_dmap<BM, BN, CONV>), pgrid, dim3(256), lds, st, g,
+            hipLaunchKernelGGL((k_gemm_f16_dmap<BM, BN, CONV, WM>), pgrid, dim3(128 * WM), lds, st, g,
                                (unsigned)a_bytes, (unsigned)w_bytes);
         } else {
-            hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV>), grid, dim3(256), lds, st, g,
+            hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV, WM>), grid, dim3(128 * WM), lds, st, g,
                                (unsigned)a_bytes, (unsigned)w_bytes);
         }
         FD_CHECK_LAUNCH("k_gemm_f16_dma");
         return FD_OK;
     }
-    static bool configured = false;
-    if (!configured && lds > 64 * 1024) {
-        FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16<BM, BN, TRANS, CONV>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
+    if constexpr (WM != 2) {
+        fd_set_error("fd_gemm_f16: 8-wave tiles need the LDS-DMA path (tensor < 2 GiB)");
+        return FD_ESHAPE;
+    } else {
+        static bool configured = false;
+        if (!configured && lds > 64 * 1024) {
+            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16<BM, BN, TRANS, CONV>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured = true;
+        }
+        hipLaunchKernelGGL((k_gemm_f16<BM, BN, TRANS, CONV>), grid, dim3(256), lds, st, g);
+        FD_CHECK_LAUNCH("k_gemm_f16");
+        return FD_OK;
     }
-    hipLaunchKernelGGL((k_gemm_f16<BM, BN, TRANS, CONV>), grid, dim3(256), lds, st, g);
-    FD_CHECK_LAUNCH("k_gemm_f16");
-    return FD_OK;
 }
 
-template <int BM, int BN, bool TRANS>
+template <int BM, int BN, bool TRANS, int WM = 2>
 static int launch(GemmArgs& g, int batch, hipStream_t st) {
-    return g.mode == MODE_CONV ? launch_mode<BM, BN, TRANS, true>(g, batch, st)
-                               : launch_mode<BM, BN, TRANS, false>(g, batch, st);
+    return g.mode == MODE_CONV ? launch_mode<BM, BN, TRANS, true, WM>(g, batch, st)
+                               : launch_mode<BM, BN, TRANS, false, WM>(g, batch, st);
 }
 
 extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
@@ -918,8 +933,15 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         best_tile = (g.M <= 64) ? 4 : 3;
     } else {
         best_tile = n160 ? 2 : 1;
+        long long tiles = tiles_wide;
+        int target = 448;                 // 2 co-resident 4-wave workgroups per CU
+        if (g.M <= 2048 && !geglu) {      // few rows: one 8-wave 256-row workgroup per CU
+            best_tile = n160 ? 5 : 6;
+            tiles = (long long)fd_cdiv(g.M, 256) * (n160 ? fd_cdiv(g.N, 160) : fd_cdiv(g.N, 128)) * batch;
+            target = 224;
+        }
         if (!geglu && batch == 1 && g.N % 4 == 0 && g.ws) {
-            while (tiles_wide * best_split < 448 && best_split < 16 &&
+            while (tiles * best_split < target && best_split < 16 &&
                    nk_all / (best_split * 2) >= 4 &&
                    (size_t)(best_split * 2) * g.M * g.N * 4 <= (size_t)d->workspace_bytes)
                 best_split *= 2;
@@ -931,13 +953,15 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         FD_CHECK_ARG(!geglu && batch == 1 && g.N % 4 == 0 && g.ws &&
                          (size_t)best_split * g.M * g.N * 4 <= (size_t)d->workspace_bytes,
                      FD_ESHAPE, "fd_gemm_f16: split_k=%d not possible for this problem", best_split);
-    if (geglu && best_tile == 2) best_tile = 1;
+    if (geglu && (best_tile == 2 || best_tile == 5)) best_tile = 1;
     g.split_k = best_split;
     fd_prof_begin(FD_FAMILY_GEMM, st, flops);
     switch (best_tile) {
         case 2: rc = launch<128, 160, false>(g, batch, st); break;
         case 3: rc = launch<128, 64, false>(g, batch, st); break;
         case 4: rc = launch<64, 64, false>(g, batch, st); break;
+        case 5: rc = launch<256, 160, false, 4>(g, batch, st); break;
+        case 6: rc = launch<256, 128, false, 4>(g, batch, st); break;
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }
     if (rc == FD_OK && g.split_k > 1) {

@@ -138,7 +138,8 @@ typedef struct fd_gemm_desc {
     /* batched GEMM over blockIdx.z: element strides per batch */
     int32_t batch;
     int64_t batch_stride_a, batch_stride_w, batch_stride_c, batch_stride_res;
-    /* scheduling: tile 0 = auto, 1 = 128x128, 2 = 128x160, 3 = 128x64, 4 = 64x64; split_k 0 =
+    /* scheduling: tile 0 = auto, 1 = 128x128, 2 = 128x160, 3 = 128x64, 4 = 64x64, 5 = 256x160 and
+     * 6 = 256x128 (8 waves); split_k 0 =
      * auto (needs `workspace`, fp32 [split_k][M][N]), 1 = off. Results are deterministic for
      * a given (shape, tile, split_k). */
     int32_t tile, split_k;

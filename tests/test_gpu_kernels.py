@@ -211,3 +211,26 @@ def test_cfg_ddim_and_layout(dev):
     close(a.t[:B * H * W, :C], want_nhwc, rtol=1e-3, atol=1e-3)
     close(a.t[B * H * W:, :C], want_nhwc, rtol=1e-3, atol=1e-3)
     assert float(a.t[:, C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('tile,split', [(1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (1, 2), (2, 4),
+                                        (5, 2), (6, 4), (3, 8)])
+def test_gemm_every_tile_and_split(dev, tile, split):
+    """Each block tile (incl. the 8-wave 256-row ones) and split-K factor gives the same
+    result as torch on a conv and on a ragged linear problem."""
+    from flexdiffuse_amd import ops
+    try:
+        ops.FORCE_TILE, ops.FORCE_SPLIT = tile, split
+        B, cin, cout, H = 2, 320, 320, 24
+        x, w, b = rnd((B, cin, H, H), 1), rnd((cout, cin, 3, 3), 2, (9 * cin) ** -0.5), rnd((cout,), 3)
+        res = rnd((B * H * H, cout), 4)
+        y = ops.conv2d(ops.nchw_to_nhwc(x.to(dev)), ops.prep_conv(w, b, dev),
+                       residual=res.half().to(dev))
+        want = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(B * H * H, cout) + res
+        close(y.t, want, rtol=3e-3, atol=3e-3)
+        M, N, K = 1000, 328, 1288
+        a, wl, bl = rnd((M, K), 5), rnd((N, K), 6, K ** -0.5), rnd((N,), 7)
+        out = ops.gemm(a.half().to(dev), ops.prep_linear(wl, bl, dev), act=ops.ACT_SILU)
+        close(out[:, :N], F.silu(a @ wl.T + bl), rtol=3e-3, atol=3e-3)
+    finally:
+        ops.FORCE_TILE, ops.FORCE_SPLIT = 0, 0
