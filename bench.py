@@ -105,6 +105,7 @@ def main():
     ap.add_argument('--preset', default='sd15')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay the UNet from a captured HIP graph')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -123,6 +124,7 @@ def main():
     sds = build.synthetic_state_dicts(args.preset, seed=0)
     cfgs = build.configs(args.preset)
     pipe, clip, tok = build.build_models(sds, args.preset, dev, vae_encoder=False)
+    pipe.use_graph = args.graph
     guide_ctx = Guide(clip, tok, device='cuda')
     enc = CLIPEncoder(clip, tok)
     B, N = args.batch, world

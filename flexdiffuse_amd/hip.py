@@ -127,8 +127,17 @@ def device_info(device: int = 0) -> dict:
             'arch': arch.value.decode()}
 
 
+_prof_on = False
+
+
 def prof_enable(on: bool):
+    global _prof_on
+    _prof_on = bool(on)
     call('fd_prof_enable', int(bool(on)))
+
+
+def prof_is_on() -> bool:
+    return _prof_on
 
 
 def prof_collect(family: int):

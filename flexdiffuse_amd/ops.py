@@ -189,11 +189,14 @@ def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[to
     return out
 
 
-def gemm_vt(a: torch.Tensor, w: LinW, B: int, rows_per_sample: int, ld: int) -> torch.Tensor:
+def gemm_vt(a: torch.Tensor, w: LinW, B: int, rows_per_sample: int, ld: int,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
     '''V projection with a transposed store: returns V^T [B][N][ld] fp16 (pad columns zero).'''
     M, K = a.shape
     assert M == B * rows_per_sample and K == w.K
-    if ld == rows_per_sample:
+    if out is not None:
+        assert out.shape == (B, w.N, ld) and out.is_contiguous()
+    elif ld == rows_per_sample:
         out = _empty((B, w.N, ld), torch.float16, a)
     else:
         out = torch.zeros((B, w.N, ld), dtype=torch.float16, device=a.device)

@@ -52,6 +52,12 @@ class FlexPipeline():
         self.device = getattr(unet, 'device', torch.device('cuda'))
         self.last_latents: Optional[torch.Tensor] = None
         self.last_images: Optional[torch.Tensor] = None
+        # opt-in: replay the UNet forward of the fused loop from a captured HIP graph (no
+        # per-kernel host launch work).  Measured on one MI355X the loop is not launch-bound
+        # (graph 5.91 vs eager 5.94 images/s), so eager launches stay the default.
+        self.use_graph = False
+        self._graphs = {}
+        self._lat_bufs = {}
 
     @classmethod
     def from_pretrained(cls, *a, **k):
@@ -93,6 +99,35 @@ class FlexPipeline():
         if pil:
             return self.numpy_to_pil(image)
         return image
+
+    def _unet_eps(self, latents: torch.Tensor, t: int, ctx: torch.Tensor, rep: int) -> torch.Tensor:
+        '''UNet noise prediction (NHWC fp32) for the fused loop; graph-replayed when enabled.
+        `latents` must be the loop's persistent buffer (updated in place by the DDIM kernel).'''
+        if not self.use_graph or hip.prof_is_on():   # event timing needs eager launches
+            return self.unet.forward_nhwc(latents, t, ctx, rep=rep)
+        self.unet.set_context(ctx)               # eager, in place: the graph reads these buffers
+        key = (latents.data_ptr(), tuple(latents.shape), rep, tuple(ctx.shape))
+        entry = self._graphs.get(key)
+        if entry is None:
+            t_static = torch.zeros((1,), dtype=torch.float32, device=latents.device)
+            # the first call runs eagerly (lazy one-time setup inside the kernels' launchers),
+            # the second is captured
+            t_static.fill_(float(t))
+            self.unet.forward_nhwc(latents, t_static, ctx, rep=rep)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eps = self.unet.forward_nhwc(latents, t_static, ctx, rep=rep)
+            entry = (graph, t_static, eps, ctx)
+            self._graphs = {key: entry}          # keep one graph (its pool holds GBs)
+        graph, t_static, eps, ctx_ref = entry
+        if ctx_ref is not ctx:
+            # a new context tensor of the same shape: K/V were re-projected in place above,
+            # nothing else in the graph depends on the tensor itself
+            pass
+        t_static.fill_(float(t))
+        graph.replay()
+        return eps
 
     def _randn(self, shape, generator):
         gdev = getattr(generator, 'device', torch.device('cpu')) if generator is not None \
@@ -152,11 +187,22 @@ class FlexPipeline():
                  and isinstance(self.scheduler, DDIMScheduler) and not eta
                  and hasattr(self.unet, 'forward_nhwc'))
         B, C, H, W = latents.shape
+        if fused and self.use_graph and not debug:
+            # persistent latent buffer: the captured UNet graph reads this address every step
+            buf = self._lat_bufs.get(tuple(latents.shape))
+            if buf is None:
+                buf = torch.empty_like(latents)
+                self._lat_bufs = {tuple(latents.shape): buf}
+            buf.copy_(latents)
+            latents = buf
         for t in self.progress_bar(self.scheduler.timesteps[t_start:]):
             if fused:
                 cfg = guide.classifier_free_guidance
-                eps = self.unet.forward_nhwc(latents, int(t), guide.stacked_embeds(),
-                                             rep=2 if cfg else 1)
+                if debug:
+                    eps = self.unet.forward_nhwc(latents, int(t), guide.stacked_embeds(),
+                                                 rep=2 if cfg else 1)
+                else:
+                    eps = self._unet_eps(latents, int(t), guide.stacked_embeds(), 2 if cfg else 1)
                 coef = self.scheduler.step_coefficients(int(t))[:4]
                 if debug:
                     latents = latents.clone()

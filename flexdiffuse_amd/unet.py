@@ -158,7 +158,14 @@ class UNet2DConditionModel():
             else ctx.reshape(Be * L, D).contiguous()
         ldv = (L + 7) // 8 * 8
         for a in self._attn_layers:
-            a.ctx_kv = (ops.gemm(c16, a.k2), ops.gemm_vt(c16, a.v2, Be, L, ldv), L)
+            old = a.ctx_kv
+            if old is not None and old[0].shape == (Be * L, a.C) and old[1].shape == (Be, a.C, ldv):
+                # same shapes as before: project in place so that a captured HIP graph of the
+                # UNet (which holds these addresses) sees the new context
+                ops.gemm(c16, a.k2, out=old[0])
+                ops.gemm_vt(c16, a.v2, Be, L, ldv, out=old[1])
+            else:
+                a.ctx_kv = (ops.gemm(c16, a.k2), ops.gemm_vt(c16, a.v2, Be, L, ldv), L)
         self._ctx_key = key
         self._ctx_ref = ctx  # keep the tensor alive so its data_ptr cannot be recycled
 

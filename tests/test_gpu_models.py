@@ -311,3 +311,20 @@ def test_runner_gen_recipe(dev):
     assert np.array_equal(np.asarray(imgs[1]), np.asarray(again[1]))
     assert not np.array_equal(np.asarray(imgs[0]), np.asarray(other[0]))
     assert r._set_seed(-5) == 0 and r._set_seed(2 ** 40) == 2147483647
+
+
+def test_hip_graph_replay_matches_eager(mini, dev):
+    """Opt-in HIP-graph replay of the UNet forward gives bit-identical latents, also when the
+    context tensor is replaced between calls (K/V are re-projected in place)."""
+    sds, pipe, clip, tok, _ = mini
+    try:
+        pipe.use_graph = False
+        _run_both(mini, dev, 3, 2, 8.0, 64)
+        eager = pipe.last_latents.clone()
+        pipe.use_graph = True
+        _run_both(mini, dev, 3, 2, 8.0, 64)
+        first = pipe.last_latents.clone()
+        _run_both(mini, dev, 3, 2, 8.0, 64)      # replays the captured graph with a new context
+        assert torch.equal(eager, first) and torch.equal(eager, pipe.last_latents)
+    finally:
+        pipe.use_graph = False
