@@ -14,7 +14,7 @@ preprocess = _encode.preprocess
 FlexPipeline = _flex.FlexPipeline
 
 from .pipeline.guide import GuideBase, PromptGuide, SimpleGuide  # noqa: E402,F401
-from .scheduler import DDIMScheduler  # noqa: E402,F401
+from .scheduler import DDIMScheduler, LMSDiscreteScheduler, PNDMScheduler  # noqa: E402,F401
 from .tokenizer import SyntheticTokenizer  # noqa: E402,F401
 from .build import build_models, synthetic_state_dicts  # noqa: E402,F401
 from .utils import Runner, image_grid  # noqa: E402,F401

@@ -299,3 +299,31 @@ extern "C" int fd_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stre
     FD_CHECK_LAUNCH("k_cast_back");
     return FD_OK;
 }
+
+// ---- rectangular blend of one latent tensor onto another (CompositeGuide, reference
+// composition/guide.py:86-98): dst[:, oy:oy+sh, ox:ox+sw] += blend * (src - dst) on NCHW fp32
+__global__ void k_region_blend(float* __restrict__ dst, const float* __restrict__ src, int C, int H,
+                               int W, int oy, int ox, int sh, int sw, float blend) {
+    const int total = C * sh * sw;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int x = e % sw, y = (e / sw) % sh, c = e / (sw * sh);
+        const size_t i = ((size_t)c * H + oy + y) * W + ox + x;
+        const float b = dst[i];
+        dst[i] = __fadd_rn(b, __fmul_rn(blend, __fsub_rn(src[i], b)));
+    }
+}
+
+extern "C" int fd_region_blend_f32(float* dst, const float* src, int C, int H, int W, int oy, int ox,
+                                   int sh, int sw, float blend, void* stream) {
+    FD_CHECK_ARG(dst && src && C > 0 && H > 0 && W > 0, FD_EINVAL, "fd_region_blend_f32: args");
+    if (oy < 0) { sh += oy; oy = 0; }
+    if (ox < 0) { sw += ox; ox = 0; }
+    if (oy + sh > H) sh = H - oy;        // python slicing clamps the box to the tensor
+    if (ox + sw > W) sw = W - ox;
+    if (sh <= 0 || sw <= 0) return FD_OK;
+    const int total = C * sh * sw;
+    hipLaunchKernelGGL(k_region_blend, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       dst, src, C, H, W, oy, ox, sh, sw, blend);
+    FD_CHECK_LAUNCH("k_region_blend");
+    return FD_OK;
+}

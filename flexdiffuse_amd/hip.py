@@ -57,6 +57,7 @@ _SIGNATURES = {
     'fd_embed_tokens_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'fd_vit_assemble_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     'fd_timestep_embedding_f16': (c_int, [P, P, c_int, c_int, P]),
+    'fd_region_blend_f32': (c_int, [P, P] + [c_int] * 7 + [c_float, P]),
     'fd_cast_f32_to_f16': (c_int, [P, P, c_int64, P]),
     'fd_cast_f16_to_f32': (c_int, [P, P, c_int64, P]),
 }

@@ -22,7 +22,7 @@ import torch
 
 from .. import hip, ops
 from ..encode.clip import preprocess
-from ..scheduler import DDIMScheduler
+from ..scheduler import DDIMScheduler, LMSDiscreteScheduler
 from .guide import GuideBase, SimpleGuide
 
 VAE_SCALE = 0.18215
@@ -165,7 +165,10 @@ class FlexPipeline():
             offset = self.scheduler.config.get('steps_offset', 0)
             init_timestep = int(guide.steps * strength) + offset
             init_timestep = min(init_timestep, guide.steps)
-            t_noise = int(self.scheduler.timesteps[-init_timestep])
+            if isinstance(self.scheduler, LMSDiscreteScheduler):
+                t_noise = guide.steps - init_timestep     # pipeline/flex.py:200-204: an index
+            else:
+                t_noise = int(self.scheduler.timesteps[-init_timestep])
             noise = self._randn(init_latents.shape, generator)
             init_latents = self.scheduler.add_noise(init_latents, noise, t_noise)
             t_start = max(guide.steps - init_timestep + offset, 0)
@@ -176,6 +179,8 @@ class FlexPipeline():
             init_latents = self._randn(shape, generator) if latents is None \
                 else latents.to(self.device, torch.float32).clone()
             self.scheduler.set_timesteps(guide.steps)
+            if isinstance(self.scheduler, LMSDiscreteScheduler):   # pipeline/flex.py:236-238
+                init_latents = ops.axpby(init_latents, None, float(self.scheduler.sigmas[0]), 0.0)
             t_start = 0
 
         accepts_eta = 'eta' in set(inspect.signature(self.scheduler.step).parameters.keys())
@@ -195,7 +200,8 @@ class FlexPipeline():
                 self._lat_bufs = {tuple(latents.shape): buf}
             buf.copy_(latents)
             latents = buf
-        for t in self.progress_bar(self.scheduler.timesteps[t_start:]):
+        is_lms = isinstance(self.scheduler, LMSDiscreteScheduler)
+        for i, t in enumerate(self.progress_bar(self.scheduler.timesteps[t_start:])):
             if fused:
                 cfg = guide.classifier_free_guidance
                 if debug:
@@ -209,8 +215,14 @@ class FlexPipeline():
                 ops.cfg_ddim_step(latents, eps, B, C, H * W, cfg, guide.guidance, coef,
                                   self.scheduler.config['prediction_type'] == 'v_prediction')
             else:
-                noise_pred = guide.noise_pred(latents, t)
-                latents = self.scheduler.step(noise_pred, t, latents, **extra_step_kwargs).prev_sample
+                t_index, model_input = t, latents
+                if is_lms:        # pipeline/flex.py:270-274: continuous-ODE input scaling
+                    t_index = t_start + i
+                    sigma = float(self.scheduler.sigmas[t_index])
+                    model_input = ops.axpby(latents, None, 1.0 / ((sigma ** 2 + 1) ** 0.5), 0.0)
+                noise_pred = guide.noise_pred(model_input, t)
+                latents = self.scheduler.step(noise_pred, t_index, latents,
+                                              **extra_step_kwargs).prev_sample
             if all_latents is not None:
                 all_latents.append(latents)
         self.last_latents = latents

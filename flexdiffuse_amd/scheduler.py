@@ -96,3 +96,152 @@ class DDIMScheduler():
         a = self.alphas_cumprod[t]
         return ops.axpby(original.to(torch.float32), noise.to(torch.float32),
                          float(np.sqrt(a)), float(np.sqrt(np.float32(1.0) - a)))
+
+
+class PNDMScheduler():
+    '''PLMS branch (skip_prk_steps=True, what Stable Diffusion v1 ships and what the reference's
+    `Runner` actually passes, utils.py:70) of diffusers 0.3.0's `PNDMScheduler`, restated
+    from the published algorithm.  PARITY UNPINNED (diffusers is not installed); the linear
+    multistep combinations run on device through fd_axpby_f32.'''
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085,
+                 beta_end: float = 0.012, beta_schedule: str = 'scaled_linear',
+                 skip_prk_steps: bool = True, steps_offset: int = 0):
+        if beta_schedule != 'scaled_linear' or not skip_prk_steps:
+            raise NotImplementedError('only the Stable-Diffusion PLMS configuration is provided')
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
+                            dtype=np.float32) ** 2
+        self.alphas_cumprod = np.cumprod(1.0 - betas, axis=0).astype(np.float32)
+        self.config = _Config(num_train_timesteps=num_train_timesteps, beta_start=beta_start,
+                              beta_end=beta_end, beta_schedule=beta_schedule,
+                              skip_prk_steps=skip_prk_steps, steps_offset=steps_offset)
+        self.timesteps = np.arange(0, num_train_timesteps)[::-1].copy()
+        self.num_inference_steps = None
+        self._offset = 0
+        self.ets, self.counter, self.cur_sample = [], 0, None
+
+    def set_format(self, tensor_format='pt'):
+        return self
+
+    def set_timesteps(self, num_inference_steps: int, offset: Optional[int] = None):
+        T = self.config['num_train_timesteps']
+        self._offset = self.config['steps_offset'] if offset is None else offset
+        self.num_inference_steps = num_inference_steps
+        base = np.arange(0, T, T // num_inference_steps) + self._offset
+        # second timestep repeated: the first PLMS step is a two-evaluation (Heun-like) start
+        self.timesteps = np.concatenate([base[:-1], base[-2:-1], base[-1:]])[::-1].copy() \
+            .astype(np.int64)
+        self.ets, self.counter, self.cur_sample = [], 0, None
+
+    def prev_coefficients(self, t: int, t_prev: int):
+        a_t = self.alphas_cumprod[t + 1 - self._offset]
+        a_p = self.alphas_cumprod[t_prev + 1 - self._offset]
+        one = np.float32(1.0)
+        sample_coeff = np.sqrt(a_p / a_t)
+        denom = a_t * np.sqrt(one - a_p) + np.sqrt(a_t * (one - a_t) * a_p)
+        return np.float32(sample_coeff), np.float32(-(a_p - a_t) / denom)
+
+    @staticmethod
+    def multistep_weights(n_ets: int):
+        return {2: (3 / 2, -1 / 2), 3: (23 / 12, -16 / 12, 5 / 12),
+                4: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}[n_ets]
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, **_):
+        t = int(timestep)
+        ratio = self.config['num_train_timesteps'] // self.num_inference_steps
+        prev = max(t - ratio, 0)
+        eps = model_output.to(torch.float32).contiguous()
+        sample = sample.to(torch.float32).contiguous()
+        if self.counter != 1:
+            self.ets.append(eps)
+        else:
+            prev, t = t, t + ratio
+        if len(self.ets) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(self.ets) == 1 and self.counter == 1:
+            eps = ops.axpby(eps, self.ets[-1], 0.5, 0.5)
+            sample, self.cur_sample = self.cur_sample, None
+        else:
+            w = self.multistep_weights(min(len(self.ets), 4))
+            acc = ops.axpby(self.ets[-1], self.ets[-2], w[0], w[1])
+            for k in range(2, len(w)):
+                acc = ops.axpby(acc, self.ets[-1 - k], 1.0, w[k])
+            eps = acc
+            self.ets = self.ets[-4:]
+        cs, ce = self.prev_coefficients(t, prev)
+        self.counter += 1
+        return SimpleNamespace(prev_sample=ops.axpby(sample, eps, float(cs), float(ce)))
+
+    def add_noise(self, original: torch.Tensor, noise: torch.Tensor, timesteps) -> torch.Tensor:
+        t = int(timesteps.reshape(-1)[0]) if isinstance(timesteps, torch.Tensor) else int(timesteps)
+        a = self.alphas_cumprod[t]
+        return ops.axpby(original.to(torch.float32), noise.to(torch.float32),
+                         float(np.sqrt(a)), float(np.sqrt(np.float32(1.0) - a)))
+
+
+class LMSDiscreteScheduler():
+    '''K-LMS (linear multistep, order 4) of diffusers 0.3.0, restated from the published
+    algorithm.  PARITY UNPINNED.  The pipeline applies the sigma input scaling exactly where
+    the reference does (pipeline/flex.py:236-238, 270-274).'''
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085,
+                 beta_end: float = 0.012, beta_schedule: str = 'scaled_linear'):
+        if beta_schedule != 'scaled_linear':
+            raise NotImplementedError(beta_schedule)
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
+                            dtype=np.float32) ** 2
+        self.alphas_cumprod = np.cumprod(1.0 - betas, axis=0).astype(np.float32)
+        self.train_sigmas = ((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5
+        self.sigmas = self.train_sigmas
+        self.config = _Config(num_train_timesteps=num_train_timesteps, beta_start=beta_start,
+                              beta_end=beta_end, beta_schedule=beta_schedule)
+        self.timesteps = np.arange(0, num_train_timesteps)[::-1].copy()
+        self.num_inference_steps = None
+        self.derivatives = []
+
+    def set_format(self, tensor_format='pt'):
+        return self
+
+    def set_timesteps(self, num_inference_steps: int):
+        T = self.config['num_train_timesteps']
+        self.num_inference_steps = num_inference_steps
+        self.timesteps = np.linspace(T - 1, 0, num_inference_steps, dtype=float)
+        low = np.floor(self.timesteps).astype(int)
+        high = np.ceil(self.timesteps).astype(int)
+        frac = np.mod(self.timesteps, 1.0)
+        s = self.train_sigmas
+        sig = (1 - frac) * s[low] + frac * s[high]
+        self.sigmas = np.concatenate([sig, [0.0]])
+        self.derivatives = []
+
+    def lms_coefficient(self, order: int, t: int, current_order: int) -> float:
+        from scipy import integrate
+
+        def f(tau):
+            prod = 1.0
+            for k in range(order):
+                if current_order == k:
+                    continue
+                prod *= (tau - self.sigmas[t - k]) / (self.sigmas[t - current_order] - self.sigmas[t - k])
+            return prod
+        return integrate.quad(f, self.sigmas[t], self.sigmas[t + 1], epsrel=1e-4)[0]
+
+    def step(self, model_output: torch.Tensor, timestep: int, sample: torch.Tensor, order: int = 4,
+             **_):
+        i = int(timestep)
+        sigma = float(self.sigmas[i])
+        sample = sample.to(torch.float32).contiguous()
+        eps = model_output.to(torch.float32).contiguous()
+        x0 = ops.axpby(sample, eps, 1.0, -sigma)
+        self.derivatives.append(ops.axpby(sample, x0, 1.0 / sigma, -1.0 / sigma))
+        if len(self.derivatives) > order:
+            self.derivatives.pop(0)
+        order = min(i + 1, order)
+        coeffs = [self.lms_coefficient(order, i, k) for k in range(order)]
+        out = sample
+        for c, d in zip(coeffs, reversed(self.derivatives)):
+            out = ops.axpby(out, d, 1.0, float(c))
+        return SimpleNamespace(prev_sample=out)
+
+    def add_noise(self, original: torch.Tensor, noise: torch.Tensor, timesteps) -> torch.Tensor:
+        i = int(timesteps.reshape(-1)[0]) if isinstance(timesteps, torch.Tensor) else int(timesteps)
+        return ops.axpby(original.to(torch.float32), noise.to(torch.float32), 1.0,
+                         float(self.sigmas[i]))

@@ -328,3 +328,67 @@ def test_hip_graph_replay_matches_eager(mini, dev):
         assert torch.equal(eager, first) and torch.equal(eager, pipe.last_latents)
     finally:
         pipe.use_graph = False
+
+
+def _eps_ref(mini):
+    from oracle import clip_ref, pipeline_ref
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = mini
+    emb = clip_ref.text_hidden(sds['clip'], ccfg, tok('a photo of a turtle').input_ids)
+    unc = clip_ref.text_hidden(sds['clip'], ccfg, tok('').input_ids)
+    return lambda x, t: pipeline_ref.noise_pred(sds['unet'], ucfg, x, t, emb, unc, 8.0)
+
+
+@pytest.mark.parametrize('kind', ['pndm', 'lms'])
+def test_pndm_and_lms_schedulers_vs_oracle(mini, dev, kind):
+    '''the PLMS scheduler the reference's Runner actually passes
+    (utils.py:70) and K-LMS incl. the pipeline's sigma scaling, vs the CPU oracle loops.'''
+    from flexdiffuse_amd import FlexPipeline, LMSDiscreteScheduler, PNDMScheduler, SimpleGuide
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from oracle import sched_ref
+    sds, pipe, clip, tok, _ = mini
+    enc = CLIPEncoder(clip, tok)
+    steps = 5        # a divisor of 1000: 0.3.0's arange-based tables are only regular then
+    sched = PNDMScheduler() if kind == 'pndm' else LMSDiscreteScheduler()
+    p2 = FlexPipeline(pipe.vae, clip, tok, pipe.unet, sched).to(dev)
+    guide = SimpleGuide(enc, pipe.unet, 8.0, steps, enc.prompt('a photo of a turtle'))
+    p2(guide=guide, init_size=(64, 64), generator=torch.Generator('cpu').manual_seed(3),
+       output_type='np')
+    lat0 = torch.randn((1, 4, 8, 8), generator=torch.Generator('cpu').manual_seed(3))
+    if kind == 'pndm':
+        want, used = sched_ref.pndm_loop(_eps_ref(mini), lat0, steps)
+        assert used == [int(t) for t in sched.timesteps] and len(used) == steps + 1
+    else:
+        want, sigmas = sched_ref.lms_loop(_eps_ref(mini), lat0, steps)
+        assert np.allclose(sigmas, sched.sigmas)
+    e = relerr(p2.last_latents, want)
+    print(f'{kind}: latent rel err {e:.4f}')
+    assert e < 2e-2, e
+
+
+def test_composite_guide_vs_oracle(mini, dev):
+    '''CompositeGuide (one UNet batch over uncond/background/entities,
+    rectangular latent blend, CFG) through the generic GuideBase protocol of the pipeline.'''
+    from flexdiffuse_amd.composition import CompositeGuide, EntitySchema, Schema
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from oracle import clip_ref, sched_ref, unet_ref, ddim_ref
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = mini
+    enc = CLIPEncoder(clip, tok)
+    schema = Schema('a forest at dawn', '', '', (0.0, 1.0),
+                    [EntitySchema('a deer', (0, 16), (64, 48), 0.8),
+                     EntitySchema('a red bird', (64, 0), (64, 64), 0.5)])
+    steps = 3
+    guide = CompositeGuide(enc, pipe.unet, 8.0, schema, steps)
+    pipe(guide=guide, init_size=(128, 128), generator=torch.Generator('cpu').manual_seed(9),
+         output_type='np')
+    th = lambda p: clip_ref.text_hidden(sds['clip'], ccfg, tok(p).input_ids)
+    ents = [(th(e.prompt), tuple(v // 8 for v in e.offset), tuple(v // 8 for v in e.size), e.blend)
+            for e in schema.entities]
+    x = torch.randn((1, 4, 16, 16), generator=torch.Generator('cpu').manual_seed(9))
+    acp = ddim_ref.alphas_cumprod()
+    for t in ddim_ref.timesteps(steps):
+        fn = lambda lat, emb: unet_ref.unet_forward(sds['unet'], ucfg, lat, int(t), emb)
+        eps = sched_ref.composite_noise_pred(fn, x, th(''), th(schema.background_prompt), ents, 8.0)
+        x = ddim_ref.ddim_step(eps, int(t), x, acp, steps)
+    e = relerr(pipe.last_latents, x)
+    print(f'composite: latent rel err {e:.4f}')
+    assert e < 2e-2, e
