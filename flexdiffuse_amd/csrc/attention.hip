@@ -28,6 +28,20 @@ struct AttnArgs {
     float scale_log2;  // softmax scale * log2(e)
 };
 
+// max over the 4 lanes {l, l^16, l^32, l^48} with the VALU lane-swap instructions
+// (v_permlane16_swap / v_permlane32_swap) instead of two LDS-path ds_bpermute round trips.
+__device__ __forceinline__ float xor_max_16_32(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned u = __float_as_uint(v);
+    auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+    const unsigned w = __float_as_uint(v);
+    auto r32 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    v = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+#endif
+    return v;
+}
+
 template <int DQK, int DV>
 __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs a) {
     constexpr int KS = DQK / 32;  // MFMA k-steps of the QK^T product
@@ -171,8 +185,7 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
             for (int f = 1; f < 4; ++f)
                 tmax = fmaxf(fmaxf(tmax, fmaxf(s[f][t][0], s[f][t][1])),
                              fmaxf(s[f][t][2], s[f][t][3]));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = xor_max_16_32(tmax);
             // running max kept in raw-score units; p = 2^(s*c2 - m*c2) as one fma + v_exp_f32
             const float mnew = fmaxf(mrow[t], tmax);
             const bool dead = mnew == -INFINITY;
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
     for (int t = 0; t < QT; ++t) {
         float l = lrow[t];
         l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l += __shfl_xor(l, 32, 64);   // once per block: the LDS-path shuffle is fine here
         const float inv = 1.0f / l;
         const int q = q0 + t * 16 + fr;
         if (q >= a.Nq) continue;
