@@ -148,7 +148,7 @@ def main():
         return out, all_latents, all_images
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -169,7 +169,7 @@ def main():
     sync()
     elapsed = time.time() - t0
     hip.prof_enable(False)
-    if world > 1:
+    if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -218,7 +218,7 @@ def main():
         if N == 1 and not args.no_parity and args.preset == 'sd15':
             line['parity'] = parity_leg(sds, cfgs, pipe, enc, tok)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

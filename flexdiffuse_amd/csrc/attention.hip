@@ -12,7 +12,7 @@
 // P goes from the softmax to the PV product without any cross-lane traffic or LDS round
 // trip.  V is consumed as V^T[d][key]; the projection GEMM's transposed-store epilogue
 // (gemm.hip) writes it in that form.  K and V^T tiles (64 keys) are staged through LDS with
-// an odd 16-byte-chunk row stride (conflict-free ds_read_b128); the next tile's global loads
+// a padded row stride (conflict-free ds_read_b128); the next tile's global loads
 // are issued before the current tile's MFMAs.
 #include "common.h"
 
@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
     constexpr int KS = DQK / 32;  // MFMA k-steps of the QK^T product
     constexpr int QT = 2;         // 16-row query tiles per wave
     constexpr int KCH = DQK / 8;  // 16-byte chunks per K row
-    constexpr int KSTR = (KCH + 1) * 16;
-    constexpr int VSTR = 9 * 16;
+    // row strides of KCH+2 / 8+2 sixteen-byte chunks: conflict-free for the ds_read_b128
+    // lane groups {0-3,12-15,20-27},... (an odd chunk stride is still 2-way conflicted)
+    constexpr int KSTR = (KCH + 2) * 16;
+    constexpr int VSTR = 10 * 16;
     constexpr int VROWS = DV * 16;
     constexpr int KLD = (64 * KCH + 255) / 256;  // K chunks per thread
     constexpr int VLD = (VROWS * 8 + 255) / 256; // V^T chunks per thread

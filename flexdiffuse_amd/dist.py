@@ -25,7 +25,9 @@ def world() -> Tuple[int, int, int]:
 
 def init(backend: str = 'nccl'):
     rank, ws, local = world()
-    if ws > 1 and not dist.is_initialized():
+    # FD_FORCE_DIST=1 initialises the process group (and runs the collectives through RCCL)
+    # even for a single rank: exercises the N > 1 code path on a 1-GPU box
+    if (ws > 1 or os.environ.get('FD_FORCE_DIST')) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         kw = {}
@@ -54,7 +56,8 @@ def shard(items, rank: int, world_size: int, per_rank: int):
 def all_gather_samples(x: torch.Tensor) -> torch.Tensor:
     '''Concatenate every rank's (B, ...) tensor along dim 0 in rank order (identity when
     not distributed).'''
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or \
+            (dist.get_world_size() == 1 and not os.environ.get('FD_FORCE_DIST')):
         return x
     x = x.contiguous()
     out = torch.empty((dist.get_world_size() * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype,
