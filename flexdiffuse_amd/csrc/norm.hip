@@ -92,19 +92,35 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ x,
     float* gr = gm + G;
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int cpg = C / G;
-    if (tid < G) {
+    // combine the per-chunk partials with all 256 threads (G groups x 256/G chunk subsets), so
+    // the streaming part of every block is not held up by a serial loop over the chunks
+    {
+        double* red = reinterpret_cast<double*>(sm + 2 * C + 2 * G);   // [2][256] doubles
+        const int g = tid % G, sub = tid / G, nsub = 256 / G;
         double s = 0.0, q = 0.0;
-        for (int k = 0; k < nchunk_stats; ++k) {
-            const float* src = part + (((size_t)b * nchunk_stats + k) * G + tid) * 2;
-            s += (double)src[0];
-            q += (double)src[1];
+        if (sub < nsub)
+            for (int k = sub; k < nchunk_stats; k += nsub) {
+                const float* src = part + (((size_t)b * nchunk_stats + k) * G + g) * 2;
+                s += (double)src[0];
+                q += (double)src[1];
+            }
+        red[tid] = s;
+        red[256 + tid] = q;
+        __syncthreads();
+        if (tid < G) {
+            s = 0.0;
+            q = 0.0;
+            for (int u = 0; u < nsub; ++u) {
+                s += red[u * G + tid];
+                q += red[256 + u * G + tid];
+            }
+            const double n = (double)HW * cpg;
+            const double mean = s / n;
+            double var = q / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            gm[tid] = (float)mean;
+            gr[tid] = (float)(1.0 / sqrt(var + (double)eps));
         }
-        const double n = (double)HW * cpg;
-        const double mean = s / n;
-        double var = q / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        gm[tid] = (float)mean;
-        gr[tid] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -185,7 +201,7 @@ extern "C" int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma,
     fd_prof_begin(FD_FAMILY_GROUPNORM, st, bytes);
     hipLaunchKernelGGL(k_gn_stats, dim3(nchunk, B), dim3(threads), lds1, st, (const half_t*)x, ws,
                        HW, C, G, PL, ppc);
-    const size_t lds2 = (size_t)(2 * C + 2 * G) * sizeof(float);
+    const size_t lds2 = (size_t)(2 * C + 2 * G) * sizeof(float) + 2 * 256 * sizeof(double) + 8;
     hipLaunchKernelGGL(k_gn_apply, dim3(nchunk, B), dim3(256), lds2, st, (const half_t*)x,
                        (half_t*)y, ws, gamma, beta, HW, C, G, nchunk, ppc, eps, silu);
     fd_prof_end(FD_FAMILY_GROUPNORM, st);

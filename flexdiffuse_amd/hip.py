@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libflexdiffuse_hip.so')
+LIB_PATH = os.environ.get('FD_LIB_PATH') or os.path.join(_HERE, 'libflexdiffuse_hip.so')
 
 FD_OK, FD_EINVAL, FD_ESHAPE, FD_EHIP = 0, -1, -2, -3
 
