@@ -195,17 +195,23 @@ def test_pipeline_errors_and_outputs(mini, dev):
     assert flag is False and len(imgs) == 3     # initial + 2 steps
 
 
-def test_sd15_c1_pipeline_psnr(dev):
+@pytest.fixture(scope='module')
+def sd15(dev):
+    from flexdiffuse_amd import build
+    sds = build.synthetic_state_dicts('sd15', seed=0)
+    pipe, clip, tok = build.build_models(sds, 'sd15', dev, vae_encoder=False)
+    return sds, pipe, clip, tok, build.configs('sd15')
+
+
+def test_sd15_c1_pipeline_psnr(sd15, dev):
     '''BASELINE configs[0] shape on the full SD1.5 architecture (859,520,964-parameter UNet,
     83.6 M VAE, CLIP ViT-L/14 text tower): 256x256, 10 DDIM steps, batch 1, CFG 8.
     GPU fp16 path vs CPU fp32 oracle on identical seeded weights, ids and CPU-drawn noise:
     integer timestep lists equal, final-image PSNR >= 40 dB, latent error reported.'''
-    from flexdiffuse_amd import SimpleGuide, build
+    from flexdiffuse_amd import SimpleGuide
     from flexdiffuse_amd.encode.clip import CLIPEncoder
     from oracle import clip_ref, pipeline_ref
-    sds = build.synthetic_state_dicts('sd15', seed=0)
-    ucfg, vcfg, ccfg = build.configs('sd15')
-    pipe, clip, tok = build.build_models(sds, 'sd15', dev, vae_encoder=False)
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = sd15
     enc = CLIPEncoder(clip, tok)
     prompt = 'a photo of a turtle in a forest, oil painting'
     steps, guidance, hw = 10, 8.0, 256
@@ -392,3 +398,37 @@ def test_composite_guide_vs_oracle(mini, dev):
     e = relerr(pipe.last_latents, x)
     print(f'composite: latent rel err {e:.4f}')
     assert e < 2e-2, e
+
+
+def test_sd15_full_size_unet_properties(sd15, dev):
+    """BASELINE configs[1] sizes (SD1.5 UNet, 64x64 latents, CFG batch 16): one sample checked
+    against the CPU oracle, and size-independent properties on the whole batch -- sample
+    independence (a sample's prediction does not depend on its batch mates, although the
+    kernels pick different tiles / split-K for M = 65536 and M = 4096), CFG with g = 1 equals
+    the conditional pass, DDIM with eps = 0 is a pure rescale."""
+    from flexdiffuse_amd import ops
+    from oracle import unet_ref
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = sd15
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((8, 4, 64, 64), generator=g)
+    ctx = torch.randn((16, 77, 768), generator=g).half().float()
+    xd, cd = x.to(dev), ctx.to(dev)
+    eps = pipe.unet.forward_nhwc(xd, 500, cd, rep=2)                       # [16*4096][4]
+    full = ops.nhwc_to_nchw(eps, 16, 4, 64, 64)
+    alone = pipe.unet(xd[3:4], 500, encoder_hidden_states=cd[11:12]).sample  # sample 3, cond half
+    assert relerr(alone, full[11:12]) < 1e-2
+    want = unet_ref.unet_forward(sds['unet'], ucfg, x[3:4], 500, ctx[11:12])
+    e = relerr(full[11:12], want)
+    print(f'full-size UNet forward vs CPU oracle: rel err {e:.4f}')
+    assert e < 3e-2
+    # CFG combine with g = 1 returns the conditional half; eps = 0 DDIM step is a rescale
+    out = torch.empty((8, 4, 64, 64), dtype=torch.float32, device=dev)
+    ops.cfg_ddim_step(None, eps, 8, 4, 4096, True, 1.0, do_step=False, eps_out=out)
+    assert torch.allclose(out, full[8:], rtol=1e-6, atol=1e-6)
+    pipe.scheduler.set_timesteps(50)
+    lat = xd.clone()
+    zero = torch.zeros((8 * 4096, 4), dtype=torch.float32, device=dev)
+    c = pipe.scheduler.step_coefficients(500)
+    ops.cfg_ddim_step(lat, zero, 8, 4, 4096, False, 1.0, c[:4])
+    acp = pipe.scheduler.alphas_cumprod
+    assert torch.allclose(lat, xd * float(np.sqrt(acp[480] / acp[500])), rtol=1e-5, atol=1e-6)
