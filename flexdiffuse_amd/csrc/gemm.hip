@@ -916,7 +916,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     }
     // ---- tile / split-K selection (deterministic; rules fitted to an exhaustive sweep of
     // every (tile, split_k) over all GEMM shapes of the SD1.5 UNet + VAE on MI355X,
-    // scratch/sweep_gemm.py, profiles/r01_gemm_sweep.txt):
+    // tools/sweep_gemm.py, profiles/r01_gemm_sweep.txt):
     //  * 128x160 has the best fragment reuse (up to 860 TFLOP/s) whenever 160 | N (all UNet
     //    widths); 128x128 otherwise (VAE widths);
     //  * short-K GEMMs (the transformer projections) are latency- not MFMA-bound: 128x64 with

@@ -12,4 +12,7 @@ w = ops.prep_conv(torch.randn((320,320,3,3))*(9*320)**-0.5, torch.randn(320), de
 for _ in range(3): ops.conv2d(x, w)
 a = torch.randn((65536,320), device=dev).half(); lw = ops.prep_linear(torch.randn((320,320))*320**-0.5, torch.randn(320), dev)
 for _ in range(3): ops.gemm(a, lw)
+gx = ops.Act(torch.randn((16*4096,320), device=dev).half(), 16, 4096, 1)
+gg = torch.ones(320, device=dev); gb = torch.zeros(320, device=dev)
+for _ in range(3): ops.groupnorm(gx, gg, gb, 32, 1e-5, True)
 torch.cuda.synchronize()
