@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
 // by the buffer descriptor's bounds check (an offset past num_records reads 0), so there is
 // no select or branch on the load path.  The K-tile offset rides in the scalar soffset, so
 // per-lane address math only runs when the filter tap changes.
-template <int BM, int BN, bool CONV, int WM>
+template <int BM, int BN, bool CONV, int WM, bool TRANS = false>
 __global__ __launch_bounds__(128 * WM) void k_gemm_f16_dma(GemmArgs g, unsigned a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses device-only builtins (host pass sees a stub)
     constexpr int NW = 2 * WM;                  // waves: WM along M x 2 along N
@@ -540,19 +540,21 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_f16_dma(GemmArgs g, unsigned 
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0,
-                                                                       0, 0);
+                    acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j],
+                                                                               acc[i][j], 0, 0, 0)
+                                      : __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i],
+                                                                               acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 #undef GEMM_DMA_TILE
-    gemm_epilogue<BM, BN, false, WM>(g, acc, m0, n0, wm, wn, fr, fq, z);
+    gemm_epilogue<BM, BN, TRANS, WM>(g, acc, m0, n0, wm, wn, fr, fq, z);
 #endif
 }
 
 // Persistent variant of the LDS-DMA loop (used for short K loops).
-template <int BM, int BN, bool CONV, int WM>
+template <int BM, int BN, bool CONV, int WM, bool TRANS = false>
 __global__ __launch_bounds__(128 * WM, 2) void k_gemm_f16_dmap(GemmArgs g, unsigned a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses device-only builtins (host pass sees a stub)
     constexpr int NW = 2 * WM;                  // waves: WM along M x 2 along N
@@ -732,8 +734,10 @@ __global__ __launch_bounds__(128 * WM, 2) void k_gemm_f16_dmap(GemmArgs g, unsig
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j],
-                                                                           0, 0, 0);
+                        acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                                fa[i], fb[j], acc[i][j], 0, 0, 0)
+                                          : __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                                fb[j], fa[i], acc[i][j], 0, 0, 0);
             }
             stage ^= 1;
             if (!last) {
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(128 * WM, 2) void k_gemm_f16_dmap(GemmArgs g, unsig
                 __syncthreads();
             }
         }
-        gemm_epilogue<BM, BN, false, WM>(g, acc, m0, n0, wm, wn, fr, fq, z);
+        gemm_epilogue<BM, BN, TRANS, WM>(g, acc, m0, n0, wm, wn, fr, fq, z);
         t = t_next;
     }
 #undef GEMM_DMA_TILE
@@ -806,12 +810,12 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         CONV ? 2ull * (g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi * g.Cin
              : 2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K);
     const unsigned long long w_bytes = 2ull * ((unsigned long long)(g.N - 1) * g.ldw + g.K);
-    if (!TRANS && g_use_dma && a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull) {
+    if (g_use_dma && a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull) {
         static bool configured = false;
         if (!configured && lds > 64 * 1024) {
-            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV, WM>),
+            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV, WM, TRANS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dmap<BM, BN, CONV, WM>),
+            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
@@ -824,10 +828,10 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
                                 (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots);
         if (persistent) {
             dim3 pgrid(g.tiles_m * g.tiles_n > slots ? slots : g.tiles_m * g.tiles_n, g.split_k, batch);
-            hipLaunchKernelGGL((k_gemm_f16_dmap<BM, BN, CONV, WM>), pgrid, dim3(128 * WM), lds, st, g,
+            hipLaunchKernelGGL((k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS>), pgrid, dim3(128 * WM), lds, st, g,
                                (unsigned)a_bytes, (unsigned)w_bytes);
         } else {
-            hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV, WM>), grid, dim3(128 * WM), lds, st, g,
+            hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV, WM, TRANS>), grid, dim3(128 * WM), lds, st, g,
                                (unsigned)a_bytes, (unsigned)w_bytes);
         }
         FD_CHECK_LAUNCH("k_gemm_f16_dma");

@@ -11,6 +11,8 @@
 //                beta into per-channel (scale, shift) in LDS, then streams the slab:
 //                y = x*scale + shift, optional SiLU.
 // Algorithmic HBM bytes: 2 B read (stats) + 2 B read + 2 B write (apply) per element.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define GN_MAX_CHUNKS 256
@@ -171,6 +173,104 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ x,
     }
 }
 
+// Small-tensor GroupNorm(+SiLU) in ONE launch (HW <= 256: the 16x16 and 8x8 UNet levels,
+// where two launches + partials are latency-, not bandwidth-bound): a workgroup owns one
+// sample x GB consecutive groups; its [HW][GB*cpg] slab is read once into registers (thread
+// t keeps the fixed 8-channel chunk t % c8 of pixels t / c8, +PL, ...), statistics are
+// reduced through LDS in a fixed order, then the same registers are normalised and stored.
+#define GN_SMALL_NV 16
+__global__ __launch_bounds__(256) void k_gn_small(const half_t* __restrict__ x, half_t* __restrict__ y,
+                                                  const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int HW, int C,
+                                                  int G, int GB, float eps, int silu) {
+    extern __shared__ float sm[];
+    const int cpg = C / G, CB = cpg * GB, c8 = CB >> 3;
+    const int PL = 256 / c8;
+    float* part = sm;                 // [PL][CB][2]
+    float* chs = sm + PL * CB * 2;    // [CB][2]
+    float* gst = chs + CB * 2;        // [GB][2] mean, rstd
+    const int b = blockIdx.y, ch0 = blockIdx.x * CB, tid = threadIdx.x;
+    const int cc = tid % c8, pl = tid / c8;
+    const bool active = pl < PL;
+    const half_t* xb = x + (size_t)b * HW * C + ch0 + cc * 8;
+    half_t* yb = y + (size_t)b * HW * C + ch0 + cc * 8;
+    uint4 v[GN_SMALL_NV];
+    float s[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = q[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN_SMALL_NV; ++i) {
+        const int p = pl + PL * i;
+        v[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (active && p < HW) v[i] = *reinterpret_cast<const uint4*>(xb + (size_t)p * C);
+    }
+#pragma unroll
+    for (int i = 0; i < GN_SMALL_NV; ++i) {
+        const half8 h = *reinterpret_cast<const half8*>(&v[i]);   // zeros beyond HW add nothing
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float f = (float)h[k];
+            s[k] += f;
+            q[k] = fmaf(f, f, q[k]);
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            part[(pl * CB + cc * 8 + k) * 2 + 0] = s[k];
+            part[(pl * CB + cc * 8 + k) * 2 + 1] = q[k];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < CB; c += 256) {
+        float a = 0.f, bq = 0.f;
+        for (int l = 0; l < PL; ++l) {
+            a += part[(l * CB + c) * 2 + 0];
+            bq += part[(l * CB + c) * 2 + 1];
+        }
+        chs[c * 2 + 0] = a;
+        chs[c * 2 + 1] = bq;
+    }
+    __syncthreads();
+    if (tid < GB) {
+        double a = 0.0, bq = 0.0;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+            a += (double)chs[c * 2 + 0];
+            bq += (double)chs[c * 2 + 1];
+        }
+        const double n = (double)HW * cpg;
+        const double mean = a / n;
+        double var = bq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        gst[tid * 2 + 0] = (float)mean;
+        gst[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    if (!active) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = cc * 8 + k, g = c / cpg;
+        const float a = gst[g * 2 + 1] * gamma[ch0 + c];
+        sc[k] = a;
+        sh[k] = beta[ch0 + c] - gst[g * 2 + 0] * a;
+    }
+#pragma unroll
+    for (int i = 0; i < GN_SMALL_NV; ++i) {
+        const int p = pl + PL * i;
+        if (p >= HW) break;
+        const half8 h = *reinterpret_cast<const half8*>(&v[i]);
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float f = fmaf((float)h[k], sc[k], sh[k]);
+            if (silu) f = f / (1.0f + __expf(-f));
+            o[k] = (half_t)f;
+        }
+        *reinterpret_cast<uint4*>(yb + (size_t)p * C) = *reinterpret_cast<uint4*>(&o);
+    }
+}
+
 extern "C" int64_t fd_groupnorm_workspace_floats(int B, int G) {
     return (int64_t)B * GN_MAX_CHUNKS * G * 2;
 }
@@ -185,6 +285,24 @@ extern "C" int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma,
     hipStream_t st = (hipStream_t)stream;
     const int c8 = C / 8;
     FD_CHECK_ARG(c8 <= 1024, FD_ESHAPE, "fd_groupnorm_nhwc_f16: C=%d too large", C);
+    // small tensors: one launch, slab in registers
+    if (getenv("FD_GN_NO_SMALL") == nullptr) {
+        const int cpg = C / G;
+        for (int GB = 1; GB <= 8 && GB <= G; GB *= 2) {
+            if (G % GB || (cpg * GB) % 8) continue;
+            const int cb8 = cpg * GB / 8;
+            if (cb8 > 256) break;
+            const int pl = 256 / cb8;
+            if ((HW + pl - 1) / pl > GN_SMALL_NV) break;
+            const size_t lds = ((size_t)pl * cpg * GB * 2 + (size_t)cpg * GB * 2 + GB * 2) * sizeof(float);
+            fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 4.0);
+            hipLaunchKernelGGL(k_gn_small, dim3(G / GB, B), dim3(256), lds, st, (const half_t*)x,
+                               (half_t*)y, gamma, beta, HW, C, G, GB, eps, silu);
+            fd_prof_end(FD_FAMILY_GROUPNORM, st);
+            FD_CHECK_LAUNCH("k_gn_small");
+            return FD_OK;
+        }
+    }
     int PL = 512 / c8;
     if (PL < 1) PL = 1;
     if (PL > HW) PL = HW;
