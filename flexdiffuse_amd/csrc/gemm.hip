@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
 // by the buffer descriptor's bounds check (an offset past num_records reads 0), so there is
 // no select or branch on the load path.  The K-tile offset rides in the scalar soffset, so
 // per-lane address math only runs when the filter tap changes.
-template <int BM, int BN, bool CONV, int WM, bool TRANS = false>
+template <int BM, int BN, bool CONV, int WM, bool TRANS = false, int NS = 2>
 __global__ __launch_bounds__(128 * WM) void k_gemm_f16_dma(GemmArgs g, unsigned a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses device-only builtins (host pass sees a stub)
     constexpr int NW = 2 * WM;                  // waves: WM along M x 2 along N
@@ -517,14 +517,32 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_f16_dma(GemmArgs g, unsigned 
         for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     GEMM_DMA_TILE(kt0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (NS == 3 && kt0 + 1 < nk) GEMM_DMA_TILE(kt0 + 1, 1);
+    if (NS == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     const int fr = lane & 15, fq = lane >> 4;
     const int frag_a = (wm * WTM + fr) * 128, frag_b = BM * 128 + (wn * WTN + fr) * 128;
     const int sw0 = ((0 * 4 + fq) ^ (fr & 7)) << 4, sw1 = ((1 * 4 + fq) ^ (fr & 7)) << 4;
+    int cur = 0;
     for (int kt = kt0; kt < nk; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        if (kt + 1 < nk) GEMM_DMA_TILE(kt + 1, cur ^ 1);
+        if (NS == 2) {
+            if (kt + 1 < nk) GEMM_DMA_TILE(kt + 1, cur ^ 1);
+        } else {
+            // 3 LDS stages: tile kt must have landed, tile kt+1 may stay in flight across the
+            // barrier (counted vmcnt + raw s_barrier: __syncthreads() would drain the DMA queue)
+            if (kt + 1 < nk) {
+                if (BG % NW == 0 || wave < BG % NW)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR + BR) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR + BR - 1) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) GEMM_DMA_TILE(kt + 2, cur == 0 ? 2 : cur - 1);
+        }
         const char* st = smem + cur * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -545,8 +563,13 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_f16_dma(GemmArgs g, unsigned 
                                       : __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i],
                                                                                acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (NS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            cur = cur == 2 ? 0 : cur + 1;
+        }
     }
 #undef GEMM_DMA_TILE
     gemm_epilogue<BM, BN, TRANS, WM>(g, acc, m0, n0, wm, wn, fr, fq, z);
@@ -799,11 +822,11 @@ static bool g_use_dma = getenv("FD_GEMM_NO_DMA") == nullptr;
 // 0 = never, 1 = short-K GEMMs only (default), 2 = always
 static int g_persist_mode = getenv("FD_GEMM_PERSIST") ? atoi(getenv("FD_GEMM_PERSIST")) : 1;
 
-template <int BM, int BN, bool TRANS, bool CONV, int WM = 2>
+template <int BM, int BN, bool TRANS, bool CONV, int WM = 2, int NS = 2>
 static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     g.tiles_m = fd_cdiv(g.M, BM);
     g.tiles_n = fd_cdiv(g.N, BN);
-    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    const size_t lds = NS * (size_t)(BM + BN) * 128;
     dim3 grid(g.tiles_m * g.tiles_n, g.split_k, batch);
     // tensor extents for the buffer descriptors of the LDS-DMA loop (must fit 32 bits)
     const unsigned long long a_bytes =
@@ -813,7 +836,7 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     if (g_use_dma && a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull) {
         static bool configured = false;
         if (!configured && lds > 64 * 1024) {
-            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV, WM, TRANS>),
+            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV, WM, TRANS, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -824,14 +847,14 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         const int occ = BM >= 256 ? 1 : (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);
         const int slots = 256 * occ;
         const int nkt = (g.K + BK - 1) / BK / g.split_k;
-        const bool persistent = g_persist_mode == 2 ||
-                                (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots);
+        const bool persistent = NS == 2 && (g_persist_mode == 2 ||
+                                (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots));
         if (persistent) {
             dim3 pgrid(g.tiles_m * g.tiles_n > slots ? slots : g.tiles_m * g.tiles_n, g.split_k, batch);
             hipLaunchKernelGGL((k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS>), pgrid, dim3(128 * WM), lds, st, g,
                                (unsigned)a_bytes, (unsigned)w_bytes);
         } else {
-            hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV, WM, TRANS>), grid, dim3(128 * WM), lds, st, g,
+            hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV, WM, TRANS, NS>), grid, dim3(128 * WM), lds, st, g,
                                (unsigned)a_bytes, (unsigned)w_bytes);
         }
         FD_CHECK_LAUNCH("k_gemm_f16_dma");
@@ -853,10 +876,10 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     }
 }
 
-template <int BM, int BN, bool TRANS, int WM = 2>
+template <int BM, int BN, bool TRANS, int WM = 2, int NS = 2>
 static int launch(GemmArgs& g, int batch, hipStream_t st) {
-    return g.mode == MODE_CONV ? launch_mode<BM, BN, TRANS, true, WM>(g, batch, st)
-                               : launch_mode<BM, BN, TRANS, false, WM>(g, batch, st);
+    return g.mode == MODE_CONV ? launch_mode<BM, BN, TRANS, true, WM, NS>(g, batch, st)
+                               : launch_mode<BM, BN, TRANS, false, WM, NS>(g, batch, st);
 }
 
 extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
@@ -957,7 +980,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         FD_CHECK_ARG(!geglu && batch == 1 && g.N % 4 == 0 && g.ws &&
                          (size_t)best_split * g.M * g.N * 4 <= (size_t)d->workspace_bytes,
                      FD_ESHAPE, "fd_gemm_f16: split_k=%d not possible for this problem", best_split);
-    if (geglu && (best_tile == 2 || best_tile == 5)) best_tile = 1;
+    if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7)) best_tile = 1;
     g.split_k = best_split;
     fd_prof_begin(FD_FAMILY_GEMM, st, flops);
     switch (best_tile) {
@@ -966,6 +989,8 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         case 4: rc = launch<64, 64, false>(g, batch, st); break;
         case 5: rc = launch<256, 160, false, 4>(g, batch, st); break;
         case 6: rc = launch<256, 128, false, 4>(g, batch, st); break;
+        case 7: rc = launch<256, 160, false, 4, 3>(g, batch, st); break;
+        case 8: rc = launch<256, 128, false, 4, 3>(g, batch, st); break;
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }
     if (rc == FD_OK && g.split_k > 1) {
