@@ -844,7 +844,7 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         }
         // Short K loops: persistent workgroups (<= 256 CUs x co-resident workgroups) walk the
         // tile list with the next tile's first K-tile prefetched under the epilogue.
-        const int occ = BM >= 256 ? 1 : (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);
+        const int occ = BM >= 256 ? 1 : (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);  // workgroups / CU
         const int slots = 256 * occ;
         const int nkt = (g.K + BK - 1) / BK / g.split_k;
         const bool persistent = NS == 2 && (g_persist_mode == 2 ||
@@ -974,13 +974,17 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                 best_split *= 2;
         }
     }
+    // without split-K the 8-wave / 32-row-wave-tile variants of the 128-row tiles (4 waves per
+    // SIMD at the same LDS footprint) hide more latency: -11 % on the 64x64-level convs
+    if (best_split == 1 && best_tile == 2) best_tile = 9;
+    if (best_split == 1 && best_tile == 1 && !geglu) best_tile = 10;
     if (d->tile) best_tile = d->tile;
     if (d->split_k > 0) best_split = d->split_k;
     if (best_split > 1)
         FD_CHECK_ARG(!geglu && batch == 1 && g.N % 4 == 0 && g.ws &&
                          (size_t)best_split * g.M * g.N * 4 <= (size_t)d->workspace_bytes,
                      FD_ESHAPE, "fd_gemm_f16: split_k=%d not possible for this problem", best_split);
-    if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7)) best_tile = 1;
+    if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7 || best_tile == 9)) best_tile = 1;
     g.split_k = best_split;
     fd_prof_begin(FD_FAMILY_GEMM, st, flops);
     switch (best_tile) {
@@ -990,6 +994,8 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         case 5: rc = launch<256, 160, false, 4>(g, batch, st); break;
         case 6: rc = launch<256, 128, false, 4>(g, batch, st); break;
         case 7: rc = launch<256, 160, false, 4, 3>(g, batch, st); break;
+        case 9: rc = launch<128, 160, false, 4>(g, batch, st); break;    // 8 waves, 32x80 wave tiles
+        case 10: rc = launch<128, 128, false, 4>(g, batch, st); break;
         case 8: rc = launch<256, 128, false, 4, 3>(g, batch, st); break;
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }
