@@ -14,6 +14,8 @@
 // (gemm.hip) writes it in that form.  K and V^T tiles (64 keys) are staged through LDS with
 // a padded row stride (conflict-free ds_read_b128); the next tile's global loads
 // are issued before the current tile's MFMAs.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct AttnArgs {
@@ -42,18 +44,21 @@ __device__ __forceinline__ float xor_max_16_32(float v) {
     return v;
 }
 
-template <int DQK, int DV>
-__global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs a) {
+// QT = 16-row query tiles per wave, NW = waves per workgroup (NW*QT*16 = 128 query rows).
+// QT=1/NW=8 trades K/V fragment reuse (2x the LDS reads) for half the registers, i.e. more
+// resident waves to hide the serial max -> exp -> PV dependency chain of the softmax.
+template <int DQK, int DV, int QT = 2, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs a) {
     constexpr int KS = DQK / 32;  // MFMA k-steps of the QK^T product
-    constexpr int QT = 2;         // 16-row query tiles per wave
+    constexpr int NT = 64 * NW;   // threads
     constexpr int KCH = DQK / 8;  // 16-byte chunks per K row
     // row strides of KCH+2 / 8+2 sixteen-byte chunks: conflict-free for the ds_read_b128
     // lane groups {0-3,12-15,20-27},... (an odd chunk stride is still 2-way conflicted)
     constexpr int KSTR = (KCH + 2) * 16;
     constexpr int VSTR = 10 * 16;
     constexpr int VROWS = DV * 16;
-    constexpr int KLD = (64 * KCH + 255) / 256;  // K chunks per thread
-    constexpr int VLD = (VROWS * 8 + 255) / 256; // V^T chunks per thread
+    constexpr int KLD = (64 * KCH + NT - 1) / NT;  // K chunks per thread
+    constexpr int VLD = (VROWS * 8 + NT - 1) / NT; // V^T chunks per thread
     constexpr int KBYTES = 64 * KSTR, VBYTES = VROWS * VSTR;
     __shared__ __attribute__((aligned(16))) char sKV[2 * (KBYTES + VBYTES)];  // two stages
 
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
     // range of the (batch, head, q-block) list so that all q-blocks of one head re-read its
     // K / V^T from the same 4 MiB L2 (without this every head's K/V is fetched by all 8 XCDs:
     // rocprofv3 FETCH_SIZE 680 MB vs 126 MB algorithmic for 16x8 heads of 4096x40)
-    const int nqb = (a.Nq + 4 * QT * 16 - 1) / (4 * QT * 16);
+    const int nqb = (a.Nq + NW * QT * 16 - 1) / (NW * QT * 16);
     const int nwg = gridDim.x;
     int id = blockIdx.x;
     {
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     const int qb = id % nqb, h = (id / nqb) % a.heads, b = id / (nqb * a.heads);
-    const int qblk0 = qb * (4 * QT * 16);
+    const int qblk0 = qb * (NW * QT * 16);
     const int q0 = qblk0 + wave * (QT * 16);
     const int d = a.d;
     const half_t* __restrict__ Qb = a.Q + (size_t)b * a.sQ + h * d;
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
 
     int ntiles = (a.Nk + 63) >> 6;
     if (a.causal) {
-        const int qend = min(a.Nq, qblk0 + 4 * QT * 16);
+        const int qend = min(a.Nq, qblk0 + NW * QT * 16);
         ntiles = min(ntiles, (qend + 63) >> 6);
     }
     const int nk8 = (a.Nk + 7) & ~7;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
         const int key0 = j * 64;
 #pragma unroll
         for (int i = 0; i < KLD; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid + NT * i;
             const int row = e / KCH, c = e - row * KCH;
             rk[i] = zero4;
             if (e < 64 * KCH && key0 + row < a.Nk && c * 8 < d)
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
         }
 #pragma unroll
         for (int i = 0; i < VLD; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid + NT * i;
             const int row = e >> 3, c = e & 7;
             rv[i] = zero4;
             if (e < VROWS * 8 && row < d && key0 + c * 8 < nk8)
@@ -134,13 +139,13 @@ __global__ __launch_bounds__(256, (DQK <= 96 ? 2 : 1)) void k_attention(AttnArgs
         char* sV = sK + KBYTES;
 #pragma unroll
         for (int i = 0; i < KLD; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid + NT * i;
             const int row = e / KCH, c = e - row * KCH;
             if (e < 64 * KCH) *reinterpret_cast<uint4*>(sK + row * KSTR + c * 16) = rk[i];
         }
 #pragma unroll
         for (int i = 0; i < VLD; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid + NT * i;
             const int row = e >> 3, c = e & 7;
             if (e < VROWS * 8) {
                 // keys 8c..8c+7 of a 32-key group -> permuted so that a lane's 8 P slots
@@ -291,18 +296,23 @@ extern "C" int fd_attention_f16(const fd_attention_desc* d, void* stream) {
                          (d->causal ? 0.5 : 1.0);
     fd_prof_begin(FD_FAMILY_ATTENTION, st, flops);
     const int hd = d->head_dim;
+    static const int wide = getenv("FD_ATTN_QT1") ? atoi(getenv("FD_ATTN_QT1")) : 1;  // measured: -5...-20 %
     if (hd <= 48) {
-        hipLaunchKernelGGL((k_attention<64, 3>), grid, dim3(256), 0, st, a);
+        if (wide) hipLaunchKernelGGL((k_attention<64, 3, 1, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_attention<64, 3>), grid, dim3(256), 0, st, a);
     } else if (hd <= 64) {
-        hipLaunchKernelGGL((k_attention<64, 4>), grid, dim3(256), 0, st, a);
+        if (wide) hipLaunchKernelGGL((k_attention<64, 4, 1, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_attention<64, 4>), grid, dim3(256), 0, st, a);
     } else if (hd <= 80) {
-        hipLaunchKernelGGL((k_attention<96, 5>), grid, dim3(256), 0, st, a);
+        if (wide) hipLaunchKernelGGL((k_attention<96, 5, 1, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_attention<96, 5>), grid, dim3(256), 0, st, a);
     } else if (hd <= 96) {
         hipLaunchKernelGGL((k_attention<96, 6>), grid, dim3(256), 0, st, a);
     } else if (hd <= 128) {
         hipLaunchKernelGGL((k_attention<128, 8>), grid, dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((k_attention<160, 10>), grid, dim3(256), 0, st, a);
+        if (wide) hipLaunchKernelGGL((k_attention<160, 10, 1, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_attention<160, 10>), grid, dim3(256), 0, st, a);
     }
     fd_prof_end(FD_FAMILY_ATTENTION, st);
     FD_CHECK_LAUNCH("k_attention");
