@@ -959,17 +959,29 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     if (g.N <= 64) {
         best_tile = (g.M <= 64) ? 4 : 3;
     } else if (g.K <= 640 || (g.K <= 1280 && tiles_wide < 512)) {
-        // short K loops (transformer projections, GEGLU, 1x1 shortcuts): latency-bound, the
-        // 8-wave tiles (4 waves per SIMD at the LDS footprint of the 4-wave ones) win by
-        // 12-23 % over 128x64; tiny row counts keep the 64x64 tile
-        best_tile = (g.M <= 1024) ? 4 : (n160 ? 9 : 10);
+        // short K loops (transformer projections, GEGLU, 1x1 shortcuts) are latency-bound:
+        // many-wave tiles win by 12-23 % over 4-wave 128x64 (16 waves on 128x160 for few rows,
+        // on 256x160 otherwise; 8 waves on 128x128 where 160 does not divide N or for GEGLU);
+        // tiny row counts keep the 64x64 tile
+        best_tile = (g.M <= 1024) ? 4 : (!n160 ? 10 : (g.M <= 4096 ? 12 : 13));
+    } else if (n160) {
+        // large K, UNet widths: 256x160 with 16 waves (32x80 wave tiles, one workgroup per CU,
+        // up to 1.23 PFLOP/s); split K until ~every CU has a workgroup
+        best_tile = 13;
+        const long long tiles = (long long)fd_cdiv(g.M, 256) * fd_cdiv(g.N, 160) * batch;
+        if (batch == 1 && g.N % 4 == 0 && g.ws) {
+            while (tiles * best_split < 224 && best_split < 16 && nk_all / (best_split * 2) >= 4 &&
+                   (size_t)(best_split * 2) * g.M * g.N * 4 <= (size_t)d->workspace_bytes)
+                best_split *= 2;
+        }
     } else {
-        best_tile = n160 ? 2 : 1;
+        // large K, other widths (VAE: 128/256/512): 128x128, 8 waves when not split
+        best_tile = 1;
         long long tiles = tiles_wide;
-        int target = 448;                 // 2 co-resident 4-wave workgroups per CU
-        if (g.M <= 2048 && !geglu) {      // few rows: one 8-wave 256-row workgroup per CU
-            best_tile = n160 ? 5 : 6;
-            tiles = (long long)fd_cdiv(g.M, 256) * (n160 ? fd_cdiv(g.N, 160) : fd_cdiv(g.N, 128)) * batch;
+        int target = 448;
+        if (g.M <= 2048 && !geglu) {
+            best_tile = 6;
+            tiles = (long long)fd_cdiv(g.M, 256) * fd_cdiv(g.N, 128) * batch;
             target = 224;
         }
         if (!geglu && batch == 1 && g.N % 4 == 0 && g.ws) {
@@ -978,18 +990,15 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                    (size_t)(best_split * 2) * g.M * g.N * 4 <= (size_t)d->workspace_bytes)
                 best_split *= 2;
         }
+        if (best_split == 1 && best_tile == 1 && !geglu) best_tile = 10;
     }
-    // without split-K the 8-wave / 32-row-wave-tile variants of the 128-row tiles (4 waves per
-    // SIMD at the same LDS footprint) hide more latency: -11 % on the 64x64-level convs
-    if (best_split == 1 && best_tile == 2) best_tile = 9;
-    if (best_split == 1 && best_tile == 1 && !geglu) best_tile = 10;
     if (d->tile) best_tile = d->tile;
     if (d->split_k > 0) best_split = d->split_k;
     if (best_split > 1)
         FD_CHECK_ARG(!geglu && batch == 1 && g.N % 4 == 0 && g.ws &&
                          (size_t)best_split * g.M * g.N * 4 <= (size_t)d->workspace_bytes,
                      FD_ESHAPE, "fd_gemm_f16: split_k=%d not possible for this problem", best_split);
-    if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7 || best_tile == 9)) best_tile = 1;
+    if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7 || best_tile == 9 || best_tile == 12 || best_tile == 13)) best_tile = 1;
     g.split_k = best_split;
     fd_prof_begin(FD_FAMILY_GEMM, st, flops);
     switch (best_tile) {
@@ -1002,6 +1011,8 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         case 9: rc = launch<128, 160, false, 4>(g, batch, st); break;    // 8 waves, 32x80 wave tiles
         case 10: rc = launch<128, 128, false, 4>(g, batch, st); break;
         case 11: rc = launch<128, 64, false, 4>(g, batch, st); break;
+        case 12: rc = launch<128, 160, false, 8>(g, batch, st); break;   // 16 waves, 16x80 wave tiles
+        case 13: rc = launch<256, 160, false, 8>(g, batch, st); break;   // 16 waves, 32x80 wave tiles
         case 8: rc = launch<256, 128, false, 4, 3>(g, batch, st); break;
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }
