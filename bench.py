@@ -45,10 +45,12 @@ def synth_prompts(n, seed=1):
     return [' '.join(rng.choice(words, size=int(rng.integers(5, 20)))) for _ in range(n)]
 
 
-def cpu_baseline(sds, cfgs, steps):
+def cpu_baseline(sds, cfgs, steps, parity_args=None):
     '''Oracle (torch fp32 restatement of the reference path) timed on the host cores over a
     bounded sample: one CFG UNet evaluation (2 forwards) of ONE image at 64x64 latents plus
-    one 512x512 VAE decode; extrapolated to steps x UNet + decode per image.'''
+    one 512x512 VAE decode; extrapolated to steps x UNet + decode per image.  With
+    `parity_args` the same leg also runs the oracle on the BASELINE configs[0] shape and
+    reports the GPU path's PSNR against it (the oracle is the checker, never the product).'''
     from oracle import unet_ref, vae_ref
     ucfg, vcfg, _ = cfgs
     g = torch.Generator().manual_seed(0)
@@ -61,7 +63,8 @@ def cpu_baseline(sds, cfgs, steps):
     vae_ref.vae_decode(sds['vae'], vcfg, x[:1])
     t_vae = time.time() - t0
     per_image = steps * t_unet + t_vae
-    return {'value': 1.0 / per_image, 'unit': 'images/sec', 'cores': torch.get_num_threads(),
+    parity = parity_leg(sds, cfgs, *parity_args) if parity_args else None
+    return {'parity': parity, 'value': 1.0 / per_image, 'unit': 'images/sec', 'cores': torch.get_num_threads(),
             'kind': 'port',
             'sample': f'1 CFG UNet evaluation (2 forwards, 1 image, 64x64 latents) = {t_unet:.2f} s '
                       f'and 1 VAE decode = {t_vae:.2f} s on {torch.get_num_threads()} threads '
@@ -214,9 +217,9 @@ def main():
         }
         if N == 1 and not args.no_cpu_baseline:
             sds32 = sds if args.preset != 'sd15' else sds
-            line['cpu_baseline'] = cpu_baseline(sds32, cfgs, args.ddim_steps)
-        if N == 1 and not args.no_parity and args.preset == 'sd15':
-            line['parity'] = parity_leg(sds, cfgs, pipe, enc, tok)
+            pargs = (pipe, enc, tok) if (not args.no_parity and args.preset == 'sd15') else None
+            line['cpu_baseline'] = cpu_baseline(sds32, cfgs, args.ddim_steps, pargs)
+            line['parity'] = line['cpu_baseline'].pop('parity')
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()
