@@ -956,7 +956,10 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     const long long tiles_wide =
         (long long)fd_cdiv(g.M, 128) * (n160 ? fd_cdiv(g.N, 160) : fd_cdiv(g.N, 128)) * batch;
     int best_tile, best_split = 1;
-    if (g.N <= 64) {
+    if (geglu) {
+        // GEGLU (K = C, N = 8C): 16 waves on 256x128 beat 8 on 128x128 by 3-10 %
+        best_tile = (g.M <= 1024) ? 11 : 14;
+    } else if (g.N <= 64) {
         best_tile = (g.M <= 64) ? 4 : 3;
     } else if (g.K <= 640 || (g.K <= 1280 && tiles_wide < 512)) {
         // short K loops (transformer projections, GEGLU, 1x1 shortcuts) are latency-bound:
@@ -975,7 +978,8 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                 best_split *= 2;
         }
     } else {
-        // large K, other widths (VAE: 128/256/512): 128x128, 8 waves when not split
+        // large K, other widths (VAE: 128/256/512): 256x128 with 16 waves when not split
+        // (2-7 % over 128x128 with 8)
         best_tile = 1;
         long long tiles = tiles_wide;
         int target = 448;
@@ -990,7 +994,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                    (size_t)(best_split * 2) * g.M * g.N * 4 <= (size_t)d->workspace_bytes)
                 best_split *= 2;
         }
-        if (best_split == 1 && best_tile == 1 && !geglu) best_tile = 10;
+        if (best_split == 1 && best_tile == 1) best_tile = (g.M >= 4096) ? 14 : 10;
     }
     if (d->tile) best_tile = d->tile;
     if (d->split_k > 0) best_split = d->split_k;
@@ -1013,6 +1017,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         case 11: rc = launch<128, 64, false, 4>(g, batch, st); break;
         case 12: rc = launch<128, 160, false, 8>(g, batch, st); break;   // 16 waves, 16x80 wave tiles
         case 13: rc = launch<256, 160, false, 8>(g, batch, st); break;   // 16 waves, 32x80 wave tiles
+        case 14: rc = launch<256, 128, false, 8>(g, batch, st); break;   // 16 waves, 32x64 wave tiles
         case 8: rc = launch<256, 128, false, 4, 3>(g, batch, st); break;
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }

@@ -70,7 +70,7 @@ for key, cnt in rec.items():
     t_auto = timeit(lambda: run(0, 0))
     best = (1e9, None)
     row = {}
-    for tile in (1,2,3,4,9,10,12,13):
+    for tile in (1,2,3,4,6,9,10,11,12,13,14):
         if act == 4 and tile in (2,5,7,9,12,13): continue
         for sk in (1,2,4,8,16):
             if sk > 1 and (act == 4 or (K//64)//sk < 4 or sk*M*N*4 > ws.numel()): continue
