@@ -18,6 +18,9 @@
 
 #include "common.h"
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 struct AttnArgs {
     const half_t* Q;
     const half_t* K;
@@ -270,6 +273,306 @@ __global__ __launch_bounds__(64 * NW, (DQK <= 96 ? 2 : 1)) void k_attention(Attn
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// 8-wave / 16-queries-per-wave variant with a VALU-lean softmax.  PMC on the N=4096 d=40
+// self-attention showed the original loop VALU-issue-bound (7.4 VALU instructions per score,
+// VALU busy ~80 %, MFMA pipe 30 %), so this one removes per-score work:
+//  * LAZY running max: scores are exponentiated against a max that is only advanced when some
+//    score exceeds it by more than 2^LAZY_THR (wave vote).  The usual tile only needs a
+//    lane-local max for the vote: no cross-lane reduce, no rescale of O, no alpha.
+//    P <= 2^LAZY_THR stays far inside fp16 range; accumulation is fp32.
+//  * PRE: Q already carries scale*log2(e) (folded into the q projection); the running max is
+//    then fed to the QK^T MFMA as its accumulator input (-m), so the MFMA result is the
+//    exponent itself: no scale/subtract pass at all.
+//  * ONES: when head_dim < 16*DV the first padding row of V^T is set to 1.0, so the PV MFMA
+//    also produces the softmax denominator (from the same fp16 P): no row-sum adds.
+//  * K / V^T tile loads are buffer loads (constant per-thread offsets, zero fill by the
+//    bounds check) instead of per-tile 64-bit address math.
+#define LAZY_THR 8.0f
+#ifndef ATT_VPRE
+#define ATT_VPRE 0
+#endif
+template <int DQK, int DV, bool PRE, bool ONES>
+__global__ __launch_bounds__(512, (DQK <= 96 ? 2 : 1)) void k_attention_w8(AttnArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KS = DQK / 32;
+    constexpr int NT = 512;
+    constexpr int KCH = DQK / 8;
+    constexpr int KSTR = (KCH + 2) * 16;
+    constexpr int VSTR = 10 * 16;
+    constexpr int VROWS = DV * 16;
+    constexpr int KLD = (64 * KCH + NT - 1) / NT;
+    constexpr int VLD = (VROWS * 8 + NT - 1) / NT;
+    constexpr int KBYTES = 64 * KSTR, VBYTES = VROWS * VSTR;
+    constexpr unsigned OOB = 0x7fffffffu;
+    __shared__ __attribute__((aligned(16))) char sKV[2 * (KBYTES + VBYTES)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int nqb = (a.Nq + 127) >> 7;
+    const int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, slot = id >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int qb = id % nqb, h = (id / nqb) % a.heads, b = id / (nqb * a.heads);
+    const int qblk0 = qb * 128;
+    const int q0 = qblk0 + wave * 16;
+    const int d = a.d;
+    const half_t* __restrict__ Qb = a.Q + (size_t)b * a.sQ + h * d;
+    const half_t* Kb = a.K + (size_t)b * a.sK + h * d;
+    const half_t* Vb = a.Vt + (size_t)b * a.sVt + (size_t)h * d * a.ldvt;
+    half_t* __restrict__ Ob = a.O + (size_t)b * a.sO + h * d;
+    const int nk8 = (a.Nk + 7) & ~7;
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Kb, 0, (unsigned)(((size_t)(a.Nk - 1) * a.ldk + d) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Vb, 0, (unsigned)(((size_t)(d - 1) * a.ldvt + nk8) * 2), 0x00020000);
+
+    half8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int q = q0 + fr, d0 = (ks * 4 + g) * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (q < a.Nq && d0 < d) v = *reinterpret_cast<const u32x4*>(Qb + (size_t)q * a.ldq + d0);
+        qf[ks] = __builtin_bit_cast(half8, v);
+    }
+
+    floatx4 o[DV];
+#pragma unroll
+    for (int dt = 0; dt < DV; ++dt) o[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float m_used = 0.f;  // running (lazy) max, in base-2 logit units
+    floatx4 init = {0.f, 0.f, 0.f, 0.f};  // PRE: -m_used, the QK^T accumulator input
+    float lrow = 0.f;
+
+    int ntiles = (a.Nk + 63) >> 6;
+    if (a.causal) {
+        const int qend = min(a.Nq, qblk0 + 128);
+        ntiles = min(ntiles, (qend + 63) >> 6);
+    }
+
+    // per-thread constant load offsets / LDS store addresses
+    unsigned kvo[KLD], vvo[VLD];
+    int krow[KLD], vkey[VLD], kst[KLD], vst[VLD];
+    bool vones[VLD], vlive[VLD];
+#pragma unroll
+    for (int i = 0; i < KLD; ++i) {
+        const int e = tid + NT * i;
+        const int row = e / KCH, c = e - row * KCH;
+        krow[i] = row;
+        kvo[i] = (e < 64 * KCH && c * 8 < d) ? (unsigned)(row * a.ldk + c * 8) * 2u : OOB;
+        kst[i] = row * KSTR + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+        const int e = tid + NT * i;
+        const int row = e >> 3, c = e & 7;
+        vkey[i] = c * 8;
+        vvo[i] = (e < VROWS * 8 && row < d) ? (unsigned)(row * a.ldvt + c * 8) * 2u : OOB;
+        vones[i] = ONES && row == d;
+        vlive[i] = e < VROWS * 8 && row < d;
+        const int grp = c >> 2, cc = c & 3;
+        const int pos = grp * 32 + (cc & 1) * 16 + (cc >> 1) * 4;  // halfs (see k_attention)
+        vst[i] = KBYTES + row * VSTR + pos * 2;
+    }
+
+    u32x4 rk[KLD], rv[VLD];
+#define ATT_LOAD(J)                                                                           \
+    {                                                                                         \
+        const int key0 = (J) * 64;                                                            \
+        if (key0 + 64 <= a.Nk) { /* full tile: constant per-lane offsets + scalar tile offset */ \
+            _Pragma("unroll") for (int i = 0; i < KLD; ++i)                                   \
+                rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, kvo[i], key0 * a.ldk * 2, 0); \
+            _Pragma("unroll") for (int i = 0; i < VLD; ++i)                                   \
+                rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, vvo[i], key0 * 2, 0);      \
+        } else { /* ragged last tile: rows / key chunks past the end read zero */             \
+            _Pragma("unroll") for (int i = 0; i < KLD; ++i) {                                 \
+                const unsigned vo = (key0 + krow[i] < a.Nk) ? kvo[i] + (unsigned)key0 * a.ldk * 2u : OOB; \
+                rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, vo, 0, 0);                 \
+            }                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < VLD; ++i) {                                 \
+                const unsigned vo = (key0 + vkey[i] < nk8) ? vvo[i] + (unsigned)key0 * 2u : OOB; \
+                rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, vo, 0, 0);                 \
+            }                                                                                 \
+        }                                                                                     \
+    }
+#define ATT_STORE(BUF)                                                                        \
+    {                                                                                         \
+        char* sb = sKV + (BUF) * (KBYTES + VBYTES);                                           \
+        _Pragma("unroll") for (int i = 0; i < KLD; ++i)                                       \
+            if (KLD * NT == 64 * KCH || tid + NT * i < 64 * KCH)                              \
+                *reinterpret_cast<u32x4*>(sb + kst[i]) = rk[i];                               \
+        _Pragma("unroll") for (int i = 0; i < VLD; ++i)                                       \
+            if (vlive[i]) {                                                                   \
+                *reinterpret_cast<u32x2*>(sb + vst[i]) = u32x2{rv[i][0], rv[i][1]};           \
+                *reinterpret_cast<u32x2*>(sb + vst[i] + 16) = u32x2{rv[i][2], rv[i][3]};      \
+            }                                                                                 \
+    }
+
+    // V^T rows >= head_dim never change: zero padding, and with ONES row `d` = 1.0 so that the
+    // PV MFMA also accumulates the softmax denominator.  Written once, to both stages.
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+        const int e = tid + NT * i;
+        if (e < VROWS * 8 && !vlive[i]) {
+            const unsigned w = vones[i] ? 0x3C003C00u : 0u;
+#pragma unroll
+            for (int buf = 0; buf < 2; ++buf) {
+                char* sb = sKV + buf * (KBYTES + VBYTES);
+                *reinterpret_cast<u32x2*>(sb + vst[i]) = u32x2{w, w};
+                *reinterpret_cast<u32x2*>(sb + vst[i] + 16) = u32x2{w, w};
+            }
+        }
+    }
+    ATT_LOAD(0);
+    ATT_STORE(0);
+    __syncthreads();
+    const float c2 = a.scale_log2;
+    const floatx2 c2v = {c2, c2};
+
+    for (int j = 0; j < ntiles; ++j) {
+        if (j + 1 < ntiles) ATT_LOAD(j + 1);
+        const char* sK = sKV + (j & 1) * (KBYTES + VBYTES);
+        const char* sV = sK + KBYTES;
+        const bool need_mask = (j * 64 + 64 > a.Nk) || a.causal;
+        floatx4 s[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 kf = *reinterpret_cast<const half8*>(sK + (f * 16 + fr) * KSTR +
+                                                                 (ks * 4 + g) * 16);
+                s[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], ks == 0 ? init : s[f], 0, 0, 0);
+            }
+#if ATT_VPRE
+        // issue the V^T fragment reads before the softmax so their latency hides under it
+        constexpr int VP = DV <= 5 ? DV : 0;
+        half8 vfp[2][VP > 0 ? VP : 1];
+        if (VP > 0) {
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+                for (int dt = 0; dt < VP; ++dt)
+                    vfp[kg][dt] = *reinterpret_cast<const half8*>(sV + (dt * 16 + fr) * VSTR +
+                                                                  (kg * 4 + g) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+        if (!PRE) {
+            const floatx2 mv = {m_used, m_used};
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    floatx2 x = {s[f][r], s[f][r + 1]};
+                    x = x * c2v - mv;
+                    s[f][r] = x[0];
+                    s[f][r + 1] = x[1];
+                }
+        }
+        if (need_mask) {
+            const int q = q0 + fr;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = j * 64 + f * 16 + g * 4 + r;
+                    if (key >= a.Nk || (a.causal && key > q)) s[f][r] = -INFINITY;
+                }
+        }
+        // s = base-2 logits relative to the lazy max.  Lane-local max as 8 v_max3_f32: fmaxf()
+        // makes the compiler canonicalise every MFMA result first (16 extra v_max per tile)
+        float tmax;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[0][3]), "v"(s[1][0]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[1][1]), "v"(s[1][2]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[1][3]), "v"(s[2][0]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[2][1]), "v"(s[2][2]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[2][3]), "v"(s[3][0]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[3][1]), "v"(s[3][2]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(tmax), "v"(s[3][3]));
+        if (j == 0 || __any(tmax > LAZY_THR)) {
+            // advance the running max to the exact row max (rare after the first tiles)
+            const float t = xor_max_16_32(tmax);
+            float delta = (j == 0) ? t : fmaxf(t, 0.f);
+            if (delta == -INFINITY) delta = 0.f;
+            const float alpha = (j == 0) ? 1.f : __builtin_amdgcn_exp2f(-delta);
+            m_used += delta;
+            if (PRE) init = floatx4{-m_used, -m_used, -m_used, -m_used};
+            lrow *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DV; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[f][r] -= delta;
+        }
+        half8 p[2];
+        floatx2 ps = {0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const floatx2 e = {__builtin_amdgcn_exp2f(s[f][r]), __builtin_amdgcn_exp2f(s[f][r + 1])};
+                if (!ONES) ps += e;
+                const half2v eh = __builtin_convertvector(e, half2v);
+                p[f >> 1][(f & 1) * 4 + r] = eh[0];
+                p[f >> 1][(f & 1) * 4 + r + 1] = eh[1];
+            }
+        if (!ONES) lrow += ps[0] + ps[1];
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+            for (int dt = 0; dt < DV; ++dt) {
+#if ATT_VPRE
+                const half8 vf = VP > 0 ? vfp[kg][VP > 0 ? dt : 0]
+                                        : *reinterpret_cast<const half8*>(sV + (dt * 16 + fr) * VSTR +
+                                                                          (kg * 4 + g) * 16);
+#else
+                const half8 vf = *reinterpret_cast<const half8*>(sV + (dt * 16 + fr) * VSTR +
+                                                                 (kg * 4 + g) * 16);
+#endif
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, p[kg], o[dt], 0, 0, 0);
+            }
+        if (j + 1 < ntiles) ATT_STORE((j + 1) & 1);
+        __syncthreads();
+    }
+#undef ATT_LOAD
+#undef ATT_STORE
+
+    float l;
+    if (ONES) {
+        // denominator = O^T row d: lane group g = (d>>2)&3, fragment d>>4, element 0
+        float lv = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DV; ++dt)
+            if (dt == (d >> 4)) lv = o[dt][0];
+        l = __shfl(lv, ((d >> 2) & 3) * 16 + fr, 64);
+    } else {
+        l = lrow;
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+    }
+    const float inv = 1.0f / l;
+    const int q = q0 + fr;
+    if (q < a.Nq) {
+#pragma unroll
+        for (int dt = 0; dt < DV; ++dt) {
+            const int d0 = dt * 16 + g * 4;
+            if (d0 >= d) continue;
+            half4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[dt][r] * inv);
+            *reinterpret_cast<half4*>(Ob + (size_t)q * a.ldo + d0) = v;
+        }
+    }
+#endif
+}
+
 extern "C" int fd_attention_f16(const fd_attention_desc* d, void* stream) {
     FD_CHECK_ARG(d && d->Q && d->K && d->Vt && d->O, FD_EINVAL, "fd_attention_f16: null pointer");
     FD_CHECK_ARG(d->batch > 0 && d->heads > 0 && d->n_q > 0 && d->n_k > 0, FD_EINVAL,
@@ -290,30 +593,47 @@ extern "C" int fd_attention_f16(const fd_attention_desc* d, void* stream) {
     a.causal = d->causal;
     const float scale = d->scale > 0.f ? d->scale : 1.0f / sqrtf((float)d->head_dim);
     a.scale_log2 = scale * 1.4426950408889634f;
+    if (d->q_prescaled) a.scale_log2 = 1.0f;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(fd_cdiv(d->n_q, 128) * d->heads * d->batch);
     const double flops = 4.0 * (double)d->batch * d->heads * (double)d->n_q * d->n_k * d->head_dim *
                          (d->causal ? 0.5 : 1.0);
     fd_prof_begin(FD_FAMILY_ATTENTION, st, flops);
     const int hd = d->head_dim;
-    static const int wide = getenv("FD_ATTN_QT1") ? atoi(getenv("FD_ATTN_QT1")) : 1;  // measured: -5...-20 %
+    // FD_ATTN_QT1: 0 = 4-wave / 32-query kernel, 1 = 8-wave kernel with the exact running max,
+    // 2 (default) = 8-wave kernel with the VALU-lean softmax (lazy max, fused denominator)
+    static const int wide = getenv("FD_ATTN_QT1") ? atoi(getenv("FD_ATTN_QT1")) : 2;
+    const bool pre = d->q_prescaled != 0;
+    FD_CHECK_ARG(!pre || (wide == 2 && (hd <= 80 || hd > 128)), FD_ESHAPE,
+                 "fd_attention_f16: q_prescaled is not supported for head_dim=%d", hd);
+#define ATT_W8(DQK, DV, ONES)                                                                  \
+    {                                                                                          \
+        if (pre) hipLaunchKernelGGL((k_attention_w8<DQK, DV, true, ONES>), grid, dim3(512), 0, st, a); \
+        else hipLaunchKernelGGL((k_attention_w8<DQK, DV, false, ONES>), grid, dim3(512), 0, st, a);    \
+    }
     if (hd <= 48) {
-        if (wide) hipLaunchKernelGGL((k_attention<64, 3, 1, 8>), grid, dim3(512), 0, st, a);
+        if (wide == 2 && hd <= 40) ATT_W8(64, 3, true)
+        else if (wide == 2) ATT_W8(64, 3, false)
+        else if (wide) hipLaunchKernelGGL((k_attention<64, 3, 1, 8>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_attention<64, 3>), grid, dim3(256), 0, st, a);
     } else if (hd <= 64) {
-        if (wide) hipLaunchKernelGGL((k_attention<64, 4, 1, 8>), grid, dim3(512), 0, st, a);
+        if (wide == 2) ATT_W8(64, 4, false)
+        else if (wide) hipLaunchKernelGGL((k_attention<64, 4, 1, 8>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_attention<64, 4>), grid, dim3(256), 0, st, a);
     } else if (hd <= 80) {
-        if (wide) hipLaunchKernelGGL((k_attention<96, 5, 1, 8>), grid, dim3(512), 0, st, a);
+        if (wide == 2) ATT_W8(96, 5, false)
+        else if (wide) hipLaunchKernelGGL((k_attention<96, 5, 1, 8>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_attention<96, 5>), grid, dim3(256), 0, st, a);
     } else if (hd <= 96) {
         hipLaunchKernelGGL((k_attention<96, 6>), grid, dim3(256), 0, st, a);
     } else if (hd <= 128) {
         hipLaunchKernelGGL((k_attention<128, 8>), grid, dim3(256), 0, st, a);
     } else {
-        if (wide) hipLaunchKernelGGL((k_attention<160, 10, 1, 8>), grid, dim3(512), 0, st, a);
+        if (wide == 2) ATT_W8(160, 10, false)
+        else if (wide) hipLaunchKernelGGL((k_attention<160, 10, 1, 8>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_attention<160, 10>), grid, dim3(256), 0, st, a);
     }
+#undef ATT_W8
     fd_prof_end(FD_FAMILY_ATTENTION, st);
     FD_CHECK_LAUNCH("k_attention");
     return FD_OK;

@@ -62,6 +62,7 @@ _SIGNATURES = {
     'fd_cast_f16_to_f32': (c_int, [P, P, c_int64, P]),
 }
 
+ABI_VERSION = 2   # FD_ABI_VERSION in include/flexdiffuse_hip.h
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -83,7 +84,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)   # AttributeError if the .so is stale
             fn.restype = res
             fn.argtypes = args
-        if handle.fd_abi_version() != 1:
+        if handle.fd_abi_version() != ABI_VERSION:
             raise RuntimeError('libflexdiffuse_hip.so ABI version mismatch; rebuild')
         _lib = handle
     return _lib

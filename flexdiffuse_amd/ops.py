@@ -3,6 +3,7 @@ memory + streams only) and launches the HIP kernels.  No arithmetic happens here
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_float, c_int32, c_int64, c_void_p
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -39,7 +40,8 @@ class fd_attention_desc(ctypes.Structure):
                 ('vt_sample_stride', c_int64), ('o_sample_stride', c_int64),
                 ('ldq', c_int32), ('ldk', c_int32), ('ldvt', c_int32), ('ldo', c_int32),
                 ('batch', c_int32), ('heads', c_int32), ('n_q', c_int32), ('n_k', c_int32),
-                ('head_dim', c_int32), ('causal', c_int32), ('scale', c_float)]
+                ('head_dim', c_int32), ('causal', c_int32), ('scale', c_float),
+                ('q_prescaled', c_int32)]
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -266,9 +268,19 @@ def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), 
 
 
 # ------------------------------------------------------------------------------ attention
+QK_LOG2E = 1.4426950408889634
+
+
+def attention_accepts_prescaled(head_dim: int) -> bool:
+    '''True when fd_attention_f16 takes q_prescaled for this head_dim (the VALU-lean 8-wave
+    kernels; FD_ATTN_QT1=0/1 selects the older kernels for A/B runs).'''
+    return os.environ.get('FD_ATTN_QT1', '2') == '2' and (head_dim <= 80 or head_dim > 128)
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, heads: int, n_q: int,
-              n_k: int, head_dim: int, causal: bool = False) -> torch.Tensor:
-    '''q [B*n_q][C], k [B*n_k][C], vt [B][C][ldvt] -> [B*n_q][C] fp16.'''
+              n_k: int, head_dim: int, causal: bool = False, q_prescaled: bool = False) -> torch.Tensor:
+    '''q [B*n_q][C], k [B*n_k][C], vt [B][C][ldvt] -> [B*n_q][C] fp16.  q_prescaled: q already
+    carries head_dim^-0.5 * log2(e) (see QK_LOG2_SCALE / prep_linear(..., scale=)).'''
     out = _empty((B * n_q, heads * head_dim), torch.float16, q)
     d = fd_attention_desc()
     d.Q, d.K, d.Vt, d.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
@@ -276,7 +288,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, heads:
     d.q_sample_stride, d.k_sample_stride = n_q * q.stride(0), n_k * k.stride(0)
     d.vt_sample_stride, d.o_sample_stride = vt.stride(0), n_q * out.stride(0)
     d.batch, d.heads, d.n_q, d.n_k, d.head_dim = B, heads, n_q, n_k, head_dim
-    d.causal, d.scale = int(causal), 0.0
+    d.causal, d.scale, d.q_prescaled = int(causal), 0.0, int(q_prescaled)
     hip.call('fd_attention_f16', ctypes.byref(d), hip.stream())
     return out
 

@@ -49,11 +49,17 @@ class _Attn:
         tb = '.transformer_blocks.0'
         self.ln = [(ops.f32(g(f'{tb}.norm{i}.weight'), dev), ops.f32(g(f'{tb}.norm{i}.bias'), dev))
                    for i in (1, 2, 3)]
-        self.q1 = ops.prep_linear(g(f'{tb}.attn1.to_q.weight'), None, dev)
+        # the softmax scale (and the base-2 conversion) is folded into the q projections, so the
+        # attention kernel exponentiates K.Q^T directly (fd_attention_desc.q_prescaled)
+        wq = g(f'{tb}.attn1.to_q.weight')
+        d = wq.shape[0] // heads
+        self.q_pre = ops.attention_accepts_prescaled(d)
+        qs = ops.QK_LOG2E * d ** -0.5 if self.q_pre else 1.0
+        self.q1 = ops.prep_linear(wq.float() * qs, None, dev)
         self.k1 = ops.prep_linear(g(f'{tb}.attn1.to_k.weight'), None, dev)
         self.v1 = ops.prep_linear(g(f'{tb}.attn1.to_v.weight'), None, dev)
         self.o1 = ops.prep_linear(g(f'{tb}.attn1.to_out.0.weight'), g(f'{tb}.attn1.to_out.0.bias'), dev)
-        self.q2 = ops.prep_linear(g(f'{tb}.attn2.to_q.weight'), None, dev)
+        self.q2 = ops.prep_linear(g(f'{tb}.attn2.to_q.weight').float() * qs, None, dev)
         self.k2 = ops.prep_linear(g(f'{tb}.attn2.to_k.weight'), None, dev)
         self.v2 = ops.prep_linear(g(f'{tb}.attn2.to_v.weight'), None, dev)
         self.o2 = ops.prep_linear(g(f'{tb}.attn2.to_out.0.weight'), g(f'{tb}.attn2.to_out.0.bias'), dev)
@@ -186,11 +192,11 @@ class UNet2DConditionModel():
         n = ops.layernorm(h, *a.ln[0])
         q, k = ops.gemm(n, a.q1), ops.gemm(n, a.k1)
         vt = ops.gemm_vt(n, a.v1, B, HW, (HW + 7) // 8 * 8)
-        o = ops.attention(q, k, vt, B, a.heads, HW, HW, d)
+        o = ops.attention(q, k, vt, B, a.heads, HW, HW, d, q_prescaled=a.q_pre)
         h = ops.gemm(o, a.o1, residual=h)
         n = ops.layernorm(h, *a.ln[1])
         kc, vtc, L = a.ctx_kv
-        o = ops.attention(ops.gemm(n, a.q2), kc, vtc, B, a.heads, HW, L, d)
+        o = ops.attention(ops.gemm(n, a.q2), kc, vtc, B, a.heads, HW, L, d, q_prescaled=a.q_pre)
         h = ops.gemm(o, a.o2, residual=h)
         n = ops.layernorm(h, *a.ln[2])
         h = ops.gemm(ops.gemm(n, a.ff1, act=ops.ACT_GEGLU), a.ff2, residual=h)

@@ -32,7 +32,7 @@ extern "C" {
 #define FD_ESHAPE (-2) /* unsupported shape / alignment */
 #define FD_EHIP (-3)   /* HIP runtime error */
 
-#define FD_ABI_VERSION 1
+#define FD_ABI_VERSION 2
 
 int fd_abi_version(void);
 const char* fd_last_error(void);
@@ -153,7 +153,10 @@ int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);
 /* Flash attention forward (scores never leave registers).  Q [B][n_q][ldq], K [B][n_k][ldk]
  * with head h at column h*head_dim; Vt [B][heads*head_dim][ldvt] is V transposed (keys
  * contiguous; columns n_k..ldvt-1 must be finite, e.g. zero); O [B][n_q][ldo].
- * head_dim % 8 == 0, <= 160.  scale <= 0 means head_dim^-0.5.  causal: key <= query. */
+ * head_dim % 8 == 0, <= 160.  scale <= 0 means head_dim^-0.5.  causal: key <= query.
+ * q_prescaled != 0: Q already carries scale*log2(e) (e.g. folded into the q projection's
+ * weights), so K.Q^T is used directly as the base-2 logit and `scale` is ignored (head_dim <= 80
+ * or 160 only). */
 typedef struct fd_attention_desc {
     const void* Q;
     const void* K;
@@ -164,6 +167,7 @@ typedef struct fd_attention_desc {
     int32_t batch, heads, n_q, n_k, head_dim;
     int32_t causal;
     float scale;
+    int32_t q_prescaled;
 } fd_attention_desc;
 
 int fd_attention_f16(const fd_attention_desc* desc, void* stream);

@@ -168,6 +168,34 @@ def test_attention(dev, Nq, Nk, heads, d, causal):
     close(out.view(B, Nq, C), attn_ref(q, k, v, heads, causal), rtol=4e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize('Nq,Nk,heads,d,causal', [(256, 256, 8, 40, False), (1024, 1024, 2, 40, False),
+                                                  (256, 77, 8, 40, False), (64, 64, 8, 160, False),
+                                                  (256, 250, 8, 80, False), (100, 77, 8, 160, False),
+                                                  (77, 77, 12, 64, True), (130, 200, 2, 48, False),
+                                                  (192, 320, 2, 32, False)])
+def test_attention_prescaled_q(dev, Nq, Nk, heads, d, causal):
+    '''q_prescaled: Q carries head_dim^-0.5 * log2(e); the kernel feeds the running max into
+    the QK^T MFMA accumulator and (head_dim <= 40) takes the denominator from the PV MFMA.
+    The max is advanced lazily, so keys are ordered to make later tiles exceed it by far.'''
+    from flexdiffuse_amd import ops
+    assert ops.attention_accepts_prescaled(d)
+    B, C = 2, heads * d
+    q, k, v = rnd((B, Nq, C), 11), rnd((B, Nk, C), 12), rnd((B, Nk, C), 13)
+    q[0, 3] *= 6.0
+    k[0, Nk - 2] *= 6.0
+    k[1, Nk // 2:] *= 3.0    # second half of the keys scores much higher than the first
+    qs = (q * (d ** -0.5 * ops.QK_LOG2E)).half()      # what the scaled q projection would emit
+    q = qs.float() / (d ** -0.5 * ops.QK_LOG2E)       # the reference sees the same rounded q
+    k = k.half().float()
+    ld = (Nk + 7) // 8 * 8 + 8
+    vt = torch.full((B, C, ld), 7.0, dtype=torch.float16)   # finite junk beyond n_k rounded to 8
+    vt[:, :, :(Nk + 7) // 8 * 8] = 0
+    vt[:, :, :Nk] = v.transpose(1, 2).half()
+    out = ops.attention(qs.to(dev).view(B * Nq, C), k.half().to(dev).view(B * Nk, C),
+                        vt.to(dev), B, heads, Nq, Nk, d, causal, q_prescaled=True)
+    close(out.view(B, Nq, C), attn_ref(q, k, v, heads, causal), rtol=4e-3, atol=4e-3)
+
+
 def test_gemm_transposed_store_feeds_attention(dev):
     '''V projection written as V^T by the GEMM epilogue, consumed by the attention kernel.'''
     from flexdiffuse_amd import ops
