@@ -66,184 +66,231 @@ __global__ void k_gn_stats(const half_t* __restrict__ x, float* __restrict__ par
         }
     }
     __syncthreads();
-    if (tid < G) {
-        const int cpg = C / G;
-        float gs = 0.f, gq = 0.f;
-        for (int l = 0; l < PL; ++l)
-            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-                gs += sm[((size_t)l * C + c) * 2 + 0];
-                gq += sm[((size_t)l * C + c) * 2 + 1];
-            }
-        float* dst = part + (((size_t)b * gridDim.x + chunk) * G + tid) * 2;
-        dst[0] = gs;
-        dst[1] = gq;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ x,
-                                                  half_t* __restrict__ y,
-                                                  const float* __restrict__ part,
-                                                  const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, int HW, int C,
-                                                  int G, int nchunk_stats, int pix_per_chunk,
-                                                  float eps, int silu) {
-    extern __shared__ float sm[];  // [C] scale, [C] shift, [G] mean, [G] rstd
-    float* sc = sm;
-    float* sh = sm + C;
-    float* gm = sm + 2 * C;
-    float* gr = gm + G;
-    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    const int cpg = C / G;
-    // combine the per-chunk partials with all 256 threads (G groups x 256/G chunk subsets), so
-    // the streaming part of every block is not held up by a serial loop over the chunks
-    {
-        double* red = reinterpret_cast<double*>(sm + 2 * C + 2 * G);   // [2][256] doubles
-        const int g = tid % G, sub = tid / G, nsub = 256 / G;
-        double s = 0.0, q = 0.0;
-        if (sub < nsub)
-            for (int k = sub; k < nchunk_stats; k += nsub) {
-                const float* src = part + (((size_t)b * nchunk_stats + k) * G + g) * 2;
-                s += (double)src[0];
-                q += (double)src[1];
-            }
-        red[tid] = s;
-        red[256 + tid] = q;
-        __syncthreads();
-        if (tid < G) {
-            s = 0.0;
-            q = 0.0;
-            for (int u = 0; u < nsub; ++u) {
-                s += red[u * G + tid];
-                q += red[256 + u * G + tid];
-            }
-            const double n = (double)HW * cpg;
-            const double mean = s / n;
-            double var = q / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            gm[tid] = (float)mean;
-            gr[tid] = (float)(1.0 / sqrt(var + (double)eps));
-        }
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        const int g = c / cpg;
-        const float a = gr[g] * gamma[c];
-        sc[c] = a;
-        sh[c] = beta[c] - gm[g] * a;
-    }
-    __syncthreads();
-    const int c8 = C >> 3;
-    const int p0 = chunk * pix_per_chunk;
-    const int p1 = min(HW, p0 + pix_per_chunk);
-    const size_t base = ((size_t)b * HW + p0) * C;
-    const int total = (p1 - p0) * c8;
-    int e = tid;
-    for (; e + 768 < total; e += 1024) {   // 4 independent vectors in flight per lane
-        uint4 raw[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            raw[u] = *reinterpret_cast<const uint4*>(x + base + (size_t)(e + 256 * u) * 8);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c0 = ((e + 256 * u) % c8) * 8;
-            const half8 v = *reinterpret_cast<const half8*>(&raw[u]);
-            half8 o;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float f = fmaf((float)v[k], sc[c0 + k], sh[c0 + k]);
-                if (silu) f = f / (1.0f + __expf(-f));
-                o[k] = (half_t)f;
-            }
-            *reinterpret_cast<uint4*>(y + base + (size_t)(e + 256 * u) * 8) =
-                *reinterpret_cast<uint4*>(&o);
-        }
-    }
-    for (; e < total; e += 256) {
-        const int c0 = (e % c8) * 8;
-        const uint4 raw = *reinterpret_cast<const uint4*>(x + base + (size_t)e * 8);
-        const half8 v = *reinterpret_cast<const half8*>(&raw);
-        half8 o;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float f = fmaf((float)v[k], sc[c0 + k], sh[c0 + k]);
-            if (silu) f = f / (1.0f + __expf(-f));
-            o[k] = (half_t)f;
-        }
-        *reinterpret_cast<uint4*>(y + base + (size_t)e * 8) = *reinterpret_cast<uint4*>(&o);
-    }
-}
-
-// Small-tensor GroupNorm(+SiLU) in ONE launch (HW <= 256: the 16x16 and 8x8 UNet levels,
-// where two launches + partials are latency-, not bandwidth-bound): a workgroup owns one
-// sample x GB consecutive groups; its [HW][GB*cpg] slab is read once into registers (thread
-// t keeps the fixed 8-channel chunk t % c8 of pixels t / c8, +PL, ...), statistics are
-// reduced through LDS in a fixed order, then the same registers are normalised and stored.
-#define GN_SMALL_NV 16
-__global__ __launch_bounds__(256) void k_gn_small(const half_t* __restrict__ x, half_t* __restrict__ y,
-                                                  const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, int HW, int C,
-                                                  int G, int GB, float eps, int silu) {
-    extern __shared__ float sm[];
-    const int cpg = C / G, CB = cpg * GB, c8 = CB >> 3;
-    const int PL = 256 / c8;
-    float* part = sm;                 // [PL][CB][2]
-    float* chs = sm + PL * CB * 2;    // [CB][2]
-    float* gst = chs + CB * 2;        // [GB][2] mean, rstd
-    const int b = blockIdx.y, ch0 = blockIdx.x * CB, tid = threadIdx.x;
-    const int cc = tid % c8, pl = tid / c8;
-    const bool active = pl < PL;
-    const half_t* xb = x + (size_t)b * HW * C + ch0 + cc * 8;
-    half_t* yb = y + (size_t)b * HW * C + ch0 + cc * 8;
-    uint4 v[GN_SMALL_NV];
-    float s[8], q[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s[k] = q[k] = 0.f;
-#pragma unroll
-    for (int i = 0; i < GN_SMALL_NV; ++i) {
-        const int p = pl + PL * i;
-        v[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (active && p < HW) v[i] = *reinterpret_cast<const uint4*>(xb + (size_t)p * C);
-    }
-#pragma unroll
-    for (int i = 0; i < GN_SMALL_NV; ++i) {
-        const half8 h = *reinterpret_cast<const half8*>(&v[i]);   // zeros beyond HW add nothing
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float f = (float)h[k];
-            s[k] += f;
-            q[k] = fmaf(f, f, q[k]);
-        }
-    }
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            part[(pl * CB + cc * 8 + k) * 2 + 0] = s[k];
-            part[(pl * CB + cc * 8 + k) * 2 + 1] = q[k];
-        }
-    }
-    __syncthreads();
-    for (int c = tid; c < CB; c += 256) {
+    // (1) per-channel sums over the PL pixel lanes, one channel per thread; (2) per-group sums
+    // with a wavefront reduction (group g handled by wave g % nwaves).  Fixed order, no atomics.
+    const int nt = blockDim.x;
+    for (int c = tid; c < C; c += nt) {
         float a = 0.f, bq = 0.f;
+#pragma unroll 4
         for (int l = 0; l < PL; ++l) {
-            a += part[(l * CB + c) * 2 + 0];
-            bq += part[(l * CB + c) * 2 + 1];
+            a += sm[((size_t)l * C + c) * 2 + 0];
+            bq += sm[((size_t)l * C + c) * 2 + 1];
         }
-        chs[c * 2 + 0] = a;
-        chs[c * 2 + 1] = bq;
+        sm[(size_t)c * 2 + 0] = a;     // row l = 0 is only read by its own thread: safe in place
+        sm[(size_t)c * 2 + 1] = bq;
     }
     __syncthreads();
-    if (tid < GB) {
-        double a = 0.0, bq = 0.0;
-        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-            a += (double)chs[c * 2 + 0];
-            bq += (double)chs[c * 2 + 1];
+    const int cpg = C / G, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    for (int g = wave; g < G; g += nw) {
+        float a = 0.f, bq = 0.f;
+        for (int i = lane; i < cpg; i += 64) {
+            a += sm[(size_t)(g * cpg + i) * 2 + 0];
+            bq += sm[(size_t)(g * cpg + i) * 2 + 1];
+        }
+        a = fd_wave_sum(a);
+        bq = fd_wave_sum(bq);
+        if (lane == 0) {
+            float* dst = part + (((size_t)b * gridDim.x + chunk) * G + g) * 2;
+            dst[0] = a;
+            dst[1] = bq;
+        }
+    }
+}
+
+__device__ __forceinline__ float gn_act(float f, int silu) {
+    // SiLU with the hardware reciprocal (1 ulp; the result is rounded to fp16 anyway)
+    return silu ? f * __builtin_amdgcn_rcpf(1.0f + __expf(-f)) : f;
+}
+
+// y = x*scale + shift (+SiLU).  Prologue: all threads combine the per-chunk partials (fp64,
+// fixed order, loads unrolled so they are in flight together).  Then thread t owns the fixed
+// 8-channel chunk t % (C/8): its 16 coefficients live in registers and the loop is pure
+// 16-byte streaming with 4 loads in flight (same thread -> address map as k_gn_stats).
+__global__ void k_gn_apply(const half_t* __restrict__ x, half_t* __restrict__ y,
+                           const float* __restrict__ part, const float* __restrict__ gamma,
+                           const float* __restrict__ beta, int HW, int C, int G,
+                           int nchunk_stats, int PL, int pix_per_chunk, float eps, int silu) {
+    extern __shared__ float sm[];   // [2][nsub*G] doubles, then [G][2] floats (mean, rstd)
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int nt = blockDim.x, nsub = nt / G;
+    double* red = reinterpret_cast<double*>(sm);
+    float* gst = reinterpret_cast<float*>(red + 2 * nsub * G);
+    {
+        const int g = tid % G, sub = tid / G;
+        if (sub < nsub) {
+            double s = 0.0, q = 0.0;
+            const float2* src = reinterpret_cast<const float2*>(part) + ((size_t)b * nchunk_stats) * G + g;
+            int k = sub;
+            for (; k + 3 * nsub < nchunk_stats; k += 4 * nsub) {
+                float2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(k + u * nsub) * G];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s += (double)v[u].x;
+                    q += (double)v[u].y;
+                }
+            }
+            for (; k < nchunk_stats; k += nsub) {
+                const float2 v = src[(size_t)k * G];
+                s += (double)v.x;
+                q += (double)v.y;
+            }
+            red[sub * G + g] = s;
+            red[nsub * G + sub * G + g] = q;
+        }
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    if (tid < G) {
+        double s = 0.0, q = 0.0;
+        for (int u = 0; u < nsub; ++u) {
+            s += red[u * G + tid];
+            q += red[nsub * G + u * G + tid];
         }
         const double n = (double)HW * cpg;
-        const double mean = a / n;
-        double var = bq / n - mean * mean;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
         if (var < 0.0) var = 0.0;
         gst[tid * 2 + 0] = (float)mean;
         gst[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int c8 = C >> 3;
+    const int cc = tid % c8, pl = tid / c8;
+    if (pl >= PL) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = cc * 8 + k, g = c / cpg;
+        const float a = gst[g * 2 + 1] * gamma[c];
+        sc[k] = a;
+        sh[k] = beta[c] - gst[g * 2 + 0] * a;
+    }
+    const int p0 = chunk * pix_per_chunk;
+    const int p1 = min(HW, p0 + pix_per_chunk);
+    const half_t* xb = x + ((size_t)b * HW) * C + cc * 8;
+    half_t* yb = y + ((size_t)b * HW) * C + cc * 8;
+    int p = p0 + pl;
+    for (; p + 3 * PL < p1; p += 4 * PL) {
+        uint4 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            raw[u] = *reinterpret_cast<const uint4*>(xb + (size_t)(p + u * PL) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const half8 v = *reinterpret_cast<const half8*>(&raw[u]);
+            half8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (half_t)gn_act(fmaf((float)v[k], sc[k], sh[k]), silu);
+            *reinterpret_cast<uint4*>(yb + (size_t)(p + u * PL) * C) = *reinterpret_cast<uint4*>(&o);
+        }
+    }
+    for (; p < p1; p += PL) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(xb + (size_t)p * C);
+        const half8 v = *reinterpret_cast<const half8*>(&raw);
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (half_t)gn_act(fmaf((float)v[k], sc[k], sh[k]), silu);
+        *reinterpret_cast<uint4*>(yb + (size_t)p * C) = *reinterpret_cast<uint4*>(&o);
+    }
+}
+
+// Slab GroupNorm(+SiLU) in ONE launch and ONE read of x: a workgroup of NT threads owns one
+// sample x GB consecutive groups; its [HW][GB*cpg] slab is read once into registers (thread
+// t keeps the fixed 8-channel chunk t % c8 of pixels t / c8, +PL, ... -- at most NV 16-byte
+// vectors), statistics are reduced through LDS in a fixed order, then the same registers are
+// normalised and stored.  4 B of HBM traffic per element instead of 6, no partials, no second
+// launch.  <256,16> serves the 16x16 / 8x8 UNet levels, <1024,22> slabs up to ~400 KB (the
+// 64x64 and 32x32 levels whenever (HW * cpg*GB/8) / 1024 <= 22).
+template <int NT, int NV>
+__global__ __launch_bounds__(NT) void k_gn_slab(const half_t* __restrict__ x, half_t* __restrict__ y,
+                                                const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, int HW, int C,
+                                                int G, int GB, float eps, int silu) {
+    extern __shared__ float sm[];
+    const int cpg = C / G, CB = cpg * GB, c8 = CB >> 3;
+    const int PL = NT / c8;
+    const int J = NT / (CB >> 1);     // second-level partial rows
+    float* part = sm;                 // [PL][CB/2][2]  (sum, sumsq) per channel pair
+    float* part2 = sm + PL * CB;      // [J][CB/2][2]
+    float* gst = part2 + J * CB;      // [GB][2] mean, rstd
+    const int b = blockIdx.y, ch0 = blockIdx.x * CB, tid = threadIdx.x;
+    const int cc = tid % c8, pl = tid / c8;
+    const bool active = pl < PL;
+    // uniform 64-bit base + 32-bit per-lane offsets (keeps the address math out of VGPR pairs)
+    const half_t* xb = x + (size_t)b * HW * C + ch0;
+    half_t* yb = y + (size_t)b * HW * C + ch0;
+    const unsigned off0 = (unsigned)(pl * C + cc * 8), ostep = (unsigned)(PL * C);
+    // statistics per channel PAIR with v_dot2_f32_f16 (packed fp16 in, fp32 accumulate): cpg is
+    // even (checked by the launcher), so a pair never straddles two groups
+    uint4 v[NV];
+    float s[4], q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = q[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int p = pl + PL * i;
+        v[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (active && p < HW) v[i] = *reinterpret_cast<const uint4*>(xb + (off0 + ostep * i));
+    }
+    const half2v one2 = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const unsigned w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};   // zeros beyond HW add nothing
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const half2v h = __builtin_bit_cast(half2v, w[k]);
+            s[k] = __builtin_amdgcn_fdot2(h, one2, s[k], false);
+            q[k] = __builtin_amdgcn_fdot2(h, h, q[k], false);
+        }
+    }
+    const int CP = CB >> 1;           // channel pairs
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            part[(pl * CP + cc * 4 + k) * 2 + 0] = s[k];
+            part[(pl * CP + cc * 4 + k) * 2 + 1] = q[k];
+        }
+    }
+    __syncthreads();
+    {   // level 1: thread (j, c) sums pixel lanes j, j+J, ... of channel pair c
+        const int c = tid % CP, j = tid / CP;
+        if (j < J) {
+            float a = 0.f, bq = 0.f;
+            for (int l = j; l < PL; l += J) {
+                a += part[(l * CP + c) * 2 + 0];
+                bq += part[(l * CP + c) * 2 + 1];
+            }
+            part2[(j * CP + c) * 2 + 0] = a;
+            part2[(j * CP + c) * 2 + 1] = bq;
+        }
+    }
+    __syncthreads();
+    {   // level 2: one wavefront per group sums its J x cpg values (fp64, fixed order)
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int g = wave; g < GB; g += NT / 64) {
+            double a = 0.0, bq = 0.0;
+            const int ppg = cpg >> 1;   // pairs per group
+            for (int i = lane; i < J * ppg; i += 64) {
+                const int j = i / ppg, c = g * ppg + (i - j * ppg);
+                a += (double)part2[(j * CP + c) * 2 + 0];
+                bq += (double)part2[(j * CP + c) * 2 + 1];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                a += __shfl_xor(a, o, 64);
+                bq += __shfl_xor(bq, o, 64);
+            }
+            if (lane == 0) {
+                const double n = (double)HW * cpg;
+                const double mean = a / n;
+                double var = bq / n - mean * mean;
+                if (var < 0.0) var = 0.0;
+                gst[g * 2 + 0] = (float)mean;
+                gst[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+            }
+        }
     }
     __syncthreads();
     if (!active) return;
@@ -256,19 +303,50 @@ __global__ __launch_bounds__(256) void k_gn_small(const half_t* __restrict__ x, 
         sh[k] = beta[ch0 + c] - gst[g * 2 + 0] * a;
     }
 #pragma unroll
-    for (int i = 0; i < GN_SMALL_NV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int p = pl + PL * i;
         if (p >= HW) break;
         const half8 h = *reinterpret_cast<const half8*>(&v[i]);
         half8 o;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float f = fmaf((float)h[k], sc[k], sh[k]);
-            if (silu) f = f / (1.0f + __expf(-f));
-            o[k] = (half_t)f;
-        }
-        *reinterpret_cast<uint4*>(yb + (size_t)p * C) = *reinterpret_cast<uint4*>(&o);
+        for (int k = 0; k < 8; ++k) o[k] = (half_t)gn_act(fmaf((float)h[k], sc[k], sh[k]), silu);
+        *reinterpret_cast<uint4*>(yb + (off0 + ostep * i)) = *reinterpret_cast<uint4*>(&o);
+        __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+template <int NT, int NV>
+static bool gn_try_slab(const void* x, void* y, const float* gamma, const float* beta, int B,
+                        int HW, int C, int G, float eps, int silu, hipStream_t st, int* rc) {
+    const int cpg = C / G;
+    if (cpg & 1) return false;
+    for (int GB = 1; GB <= 8 && GB <= G; GB *= 2) {
+        if (G % GB || (cpg * GB) % 8) continue;
+        const int CB = cpg * GB, cb8 = CB / 8;
+        if (cb8 > NT || CB / 2 > NT) break;
+        const int pl = NT / cb8, J = NT / (CB / 2);
+        if ((HW + pl - 1) / pl > NV) break;
+        const size_t lds = ((size_t)pl * CB + (size_t)J * CB + GB * 2) * sizeof(float);
+        if (lds > 160 * 1024) break;
+        static bool attr_set = false;   // per instantiation
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_slab<NT, NV>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                fd_set_error("fd_groupnorm_nhwc_f16: cannot raise the LDS limit");
+                *rc = FD_EHIP;
+                return true;
+            }
+            attr_set = true;
+        }
+        fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 4.0);
+        hipLaunchKernelGGL((k_gn_slab<NT, NV>), dim3(G / GB, B), dim3(NT), lds, st, (const half_t*)x,
+                           (half_t*)y, gamma, beta, HW, C, G, GB, eps, silu);
+        fd_prof_end(FD_FAMILY_GROUPNORM, st);
+        *rc = hipGetLastError() == hipSuccess ? FD_OK : FD_EHIP;
+        if (*rc != FD_OK) fd_set_error("k_gn_slab: launch failed");
+        return true;
+    }
+    return false;
 }
 
 extern "C" int64_t fd_groupnorm_workspace_floats(int B, int G) {
@@ -285,23 +363,16 @@ extern "C" int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma,
     hipStream_t st = (hipStream_t)stream;
     const int c8 = C / 8;
     FD_CHECK_ARG(c8 <= 1024, FD_ESHAPE, "fd_groupnorm_nhwc_f16: C=%d too large", C);
-    // small tensors: one launch, slab in registers
-    if (getenv("FD_GN_NO_SMALL") == nullptr) {
-        const int cpg = C / G;
-        for (int GB = 1; GB <= 8 && GB <= G; GB *= 2) {
-            if (G % GB || (cpg * GB) % 8) continue;
-            const int cb8 = cpg * GB / 8;
-            if (cb8 > 256) break;
-            const int pl = 256 / cb8;
-            if ((HW + pl - 1) / pl > GN_SMALL_NV) break;
-            const size_t lds = ((size_t)pl * cpg * GB * 2 + (size_t)cpg * GB * 2 + GB * 2) * sizeof(float);
-            fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 4.0);
-            hipLaunchKernelGGL(k_gn_small, dim3(G / GB, B), dim3(256), lds, st, (const half_t*)x,
-                               (half_t*)y, gamma, beta, HW, C, G, GB, eps, silu);
-            fd_prof_end(FD_FAMILY_GROUPNORM, st);
-            FD_CHECK_LAUNCH("k_gn_small");
-            return FD_OK;
-        }
+    // slabs that fit a workgroup's registers: one launch, one read (FD_GN_NO_SMALL=1: never,
+    // =2: only the 256-thread form)
+    {
+        const char* e = getenv("FD_GN_NO_SMALL");
+        const int off = e ? atoi(e) : 0;
+        int rc = FD_OK;
+        if (off != 1 && gn_try_slab<256, 16>(x, y, gamma, beta, B, HW, C, G, eps, silu, st, &rc)) return rc;
+        // 1024-thread slabs pay off up to 32x32 maps; at 64x64 the 80-byte rows of a narrow slab
+        // waste cache lines and the two streaming passes below are as fast or faster (measured)
+        if (off == 0 && HW <= 1024 && gn_try_slab<1024, 22>(x, y, gamma, beta, B, HW, C, G, eps, silu, st, &rc)) return rc;
     }
     int PL = 512 / c8;
     if (PL < 1) PL = 1;
@@ -319,9 +390,9 @@ extern "C" int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma,
     fd_prof_begin(FD_FAMILY_GROUPNORM, st, bytes);
     hipLaunchKernelGGL(k_gn_stats, dim3(nchunk, B), dim3(threads), lds1, st, (const half_t*)x, ws,
                        HW, C, G, PL, ppc);
-    const size_t lds2 = (size_t)(2 * C + 2 * G) * sizeof(float) + 2 * 256 * sizeof(double) + 8;
-    hipLaunchKernelGGL(k_gn_apply, dim3(nchunk, B), dim3(256), lds2, st, (const half_t*)x,
-                       (half_t*)y, ws, gamma, beta, HW, C, G, nchunk, ppc, eps, silu);
+    const size_t lds2 = (size_t)2 * threads * sizeof(double) + (size_t)2 * G * sizeof(float);
+    hipLaunchKernelGGL(k_gn_apply, dim3(nchunk, B), dim3(threads), lds2, st, (const half_t*)x,
+                       (half_t*)y, (const float*)ws, gamma, beta, HW, C, G, nchunk, PL, ppc, eps, silu);
     fd_prof_end(FD_FAMILY_GROUPNORM, st);
     FD_CHECK_LAUNCH("k_gn_stats/k_gn_apply");
     return FD_OK;

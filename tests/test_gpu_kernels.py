@@ -114,7 +114,9 @@ def test_conv_small_cin_and_asym_pad(dev):
 
 @pytest.mark.parametrize('C,HW,silu,eps', [(320, 1024, True, 1e-5), (960, 256, True, 1e-5),
                                            (1280, 64, False, 1e-6), (2560, 64, True, 1e-5),
-                                           (128, 4096, True, 1e-6), (64, 256, False, 1e-6)])
+                                           (128, 4096, True, 1e-6), (64, 256, False, 1e-6),
+                                           (640, 1024, True, 1e-5), (1920, 1024, True, 1e-5),
+                                           (640, 4096, False, 1e-5), (96, 300, True, 1e-5)])
 def test_groupnorm(dev, C, HW, silu, eps):
     from flexdiffuse_amd import ops
     B = 3
