@@ -497,7 +497,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_f16_dma(GemmArgs g, unsigned 
                 if (AG % NW == 0 || i * NW + wave < AG)                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
                     rsA, (lds_ptr)(stage + (i * NW + wave) * 1024), 16,                      \
-                    kok ? a_voff[i] : a_bytes, kok ? soff : 0, 0, 0);                       \
+                    kok ? a_voff[i] : a_bytes, soff, 0, 0);                                 \
         }                                                                                   \
         {                                                                                   \
             const bool kok = (KT) * BK < ktail;                                             \
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_f16_dma(GemmArgs g, unsigned 
                 if (BG % NW == 0 || i * NW + wave < BG)                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
                     rsW, (lds_ptr)(stage + BM * 128 + (i * NW + wave) * 1024), 16,           \
-                    kok ? b_voff[i] : w_bytes, kok ? soff : 0, 0, 0);                       \
+                    kok ? b_voff[i] : w_bytes, soff, 0, 0);                                 \
         }                                                                                   \
     }
 
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(128 * WM, 2) void k_gemm_f16_dmap(GemmArgs g, unsig
                 if (AG % NW == 0 || i * NW + wave < AG)                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
                     rsA, (lds_ptr)(stage_ + (i * NW + wave) * 1024), 16,                     \
-                    kok ? a_voff[i] : a_bytes, kok ? soff : 0, 0, 0);                       \
+                    kok ? a_voff[i] : a_bytes, soff, 0, 0);                                 \
         }                                                                                   \
         {                                                                                   \
             const bool kok = (KT) * BK < ktail;                                             \
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(128 * WM, 2) void k_gemm_f16_dmap(GemmArgs g, unsig
                 if (BG % NW == 0 || i * NW + wave < BG)                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
                     rsW, (lds_ptr)(stage_ + BM * 128 + (i * NW + wave) * 1024), 16,          \
-                    kok ? b_voff[i] : w_bytes, kok ? soff : 0, 0, 0);                       \
+                    kok ? b_voff[i] : w_bytes, soff, 0, 0);                                 \
         }                                                                                   \
     }
 
