@@ -77,6 +77,18 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     }
 }
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs
+
+// v_permlane16_swap: exchanges a's odd 16-lane rows with b's even rows (lane l <-> l ^ 16)
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+#endif
+}
+
 // Fused epilogue shared by the register-staged and the LDS-DMA main loops.
 template <int BM, int BN, bool TRANS, int WM = 2>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
@@ -130,11 +142,61 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
         return;
     }
     const bool geglu = g.act == FD_ACT_GEGLU;
+    // fp16 stores: a lane owns 4 consecutive columns (8 B) of each 16-column fragment.  Two
+    // neighbouring fragments are re-paired with v_permlane16_swap so that every lane stores 8
+    // consecutive columns (16 B): half the store instructions, 64 B instead of 32 B runs per row.
+    //   even lane rows (fq 0,2) keep fragment X and receive their right neighbour's X part,
+    //   odd lane rows (fq 1,3) keep fragment Y and receive their left neighbour's Y part.
+    const int pcol = (fq & 1) * 16 + (fq >> 1) * 8;   // column of the paired 16-byte store
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * WTM + i * 16 + fr;
-        if (m >= g.M) continue;
+        if (m >= g.M) continue;   // lanes l and l^16 share fr, so swap partners stay together
         const int b = m / g.rows_per_batch;
+        if (geglu) {
+            // interleaved weight rows: even fragment = value, odd fragment = gate
+            constexpr int NP = NI / 2;
+            half4 og[NP > 0 ? NP : 1];
+#pragma unroll
+            for (int jp = 0; jp < NP; ++jp) {
+                const int j = 2 * jp;
+                const int nb0 = n0 + wn * WTN + j * 16 + fq * 4;
+                float v[4], gt[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][j][r] * g.alpha;
+                    gt[r] = acc[i][j + 1][r] * g.alpha;
+                }
+                if (g.bias && nb0 + 16 < g.N) {
+                    const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb0);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                    const float4 bg = *reinterpret_cast<const float4*>(g.bias + nb0 + 16);
+                    gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) og[jp][r] = (half_t)(v[r] * act_apply(gt[r], FD_ACT_GELU));
+            }
+            half_t* Crow = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC + (size_t)m * g.ldc;
+#pragma unroll
+            for (int jp = 0; jp < NP; jp += 2) {
+                const int cb = (n0 + wn * WTN + jp * 32) >> 1;   // first output column of block jp
+                if (jp + 1 < NP && n0 + wn * WTN + (jp + 2) * 32 <= g.N && (g.ldc & 7) == 0) {
+                    const u32x2 x = __builtin_bit_cast(u32x2, og[jp]);
+                    const u32x2 y = __builtin_bit_cast(u32x2, og[jp + 1 < NP ? jp + 1 : jp]);
+                    unsigned x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+                    swap16(x0, y0);
+                    swap16(x1, y1);
+                    *reinterpret_cast<u32x4*>(Crow + cb + pcol) = u32x4{x0, x1, y0, y1};
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (jp + u < NP && n0 + wn * WTN + (jp + u) * 32 + fq * 4 + 16 < g.N)
+                            *reinterpret_cast<half4*>(Crow + cb + u * 16 + fq * 4) = og[jp + u < NP ? jp + u : jp];
+                }
+            }
+            continue;
+        }
+        half4 oh[NI];
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int nb0 = n0 + wn * WTN + j * 16 + fq * 4;
@@ -150,24 +212,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                 const float4 bb =
                     *reinterpret_cast<const float4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
                 v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-            }
-            if (geglu) {
-                // interleaved rows: even fragment = value, odd fragment = gate
-                if (j & 1) continue;
-                float gt[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gt[r] = acc[i][j + 1 < NI ? j + 1 : j][r] * g.alpha;
-                if (g.bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb0 + 16);
-                    gt[0] += bb.x; gt[1] += bb.y; gt[2] += bb.z; gt[3] += bb.w;
-                }
-                const int no = ((n0 + wn * WTN + j * 16) >> 1) + fq * 4;
-                half4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[r] * act_apply(gt[r], FD_ACT_GELU));
-                *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC +
-                                          (size_t)m * g.ldc + no) = o;
-                continue;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], g.act);
@@ -186,15 +230,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                     for (int r = 0; r < 4 && nb0 + r < g.N; ++r) C[r] = v[r];
                 }
             } else {
-                half_t* C = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC +
-                            (size_t)m * g.ldc + nb0;
-                if (nb0 + 3 < g.N) {
-                    half4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-                    *reinterpret_cast<half4*>(C) = o;
-                } else {
-                    for (int r = 0; r < 4 && nb0 + r < g.N; ++r) C[r] = (half_t)v[r];
+                for (int r = 0; r < 4; ++r) oh[j][r] = (half_t)v[r];
+            }
+        }
+        if (g.out_f32) continue;
+        half_t* Crow = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC + (size_t)m * g.ldc;
+#pragma unroll
+        for (int j = 0; j < NI; j += 2) {
+            const int cb = n0 + wn * WTN + j * 16;
+            if (j + 1 < NI && cb + 32 <= g.N && (g.ldc & 7) == 0) {   // wave-uniform
+                const u32x2 x = __builtin_bit_cast(u32x2, oh[j]);
+                const u32x2 y = __builtin_bit_cast(u32x2, oh[j + 1 < NI ? j + 1 : j]);
+                unsigned x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+                swap16(x0, y0);
+                swap16(x1, y1);
+                *reinterpret_cast<u32x4*>(Crow + cb + pcol) = u32x4{x0, x1, y0, y1};
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (j + u >= NI) continue;
+                    const int nb0 = cb + u * 16 + fq * 4;
+                    half_t* C = Crow + nb0;
+                    const half4 o = oh[j + u < NI ? j + u : j];
+                    if (nb0 + 3 < g.N) {
+                        *reinterpret_cast<half4*>(C) = o;
+                    } else {
+                        for (int r = 0; r < 4 && nb0 + r < g.N; ++r) C[r] = o[r];
+                    }
                 }
             }
         }
@@ -202,7 +265,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
 }
 
 typedef const __attribute__((address_space(1))) half_t* gptr_h;   // force global_load (not flat)
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs
 typedef const __attribute__((address_space(1))) u32x4* gptr_u4;
 
 template <int BM, int BN, bool TRANS, bool CONV>
