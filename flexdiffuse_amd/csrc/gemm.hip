@@ -119,26 +119,56 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
     }
     // ---- epilogue -----------------------------------------------------------------------
     if (TRANS) {
-        // out[b][n][m_local]: lane holds rows m = base + fq*4 + r for column n = base + fr
+        // out[b][n][m_local]: lane holds rows m = base + fq*4 + r for column n = base + fr, i.e.
+        // 4 consecutive elements of output row n.  Row fragments i, i+1 are re-paired across
+        // lanes l <-> l^16 (v_permlane16_swap) into 8 consecutive elements = one 16-byte store.
         half_t* __restrict__ T = reinterpret_cast<half_t*>(g.C);
+        const bool vec_ok = (g.rows_per_batch & 7) == 0 && (g.ldt & 7) == 0 && (g.strideT & 7) == 0 &&
+                            (g.strideC & 7) == 0;
+        const int prow = (fq & 1) * 16 + (fq >> 1) * 8;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + fr;
+            const bool n_ok = n < g.N;
+            const float bn = (n_ok && g.bias) ? g.bias[n] : 0.f;
+            half4 oh[MI];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int n = n0 + wn * WTN + j * 16 + fr;
-                const int mb = m0 + wm * WTM + i * 16 + fq * 4;
-                if (n >= g.N) continue;
-                const float bn = g.bias ? g.bias[n] : 0.f;
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = mb + r;
-                    if (m >= g.M) continue;
-                    const int b = m / g.rows_per_batch, ml = m - b * g.rows_per_batch;
-                    const float v = act_apply(acc[i][j][r] * g.alpha + bn, g.act);
-                    T[(size_t)z * g.strideC + (size_t)b * g.strideT + (size_t)n * g.ldt + ml] =
-                        (half_t)v;
+                for (int r = 0; r < 4; ++r) oh[i][r] = (half_t)act_apply(acc[i][j][r] * g.alpha + bn, g.act);
+#pragma unroll
+            for (int i = 0; i < MI; i += 2) {
+                const int mblk = m0 + wm * WTM + i * 16;           // 32-row block (wave-uniform)
+                const int bb = mblk / g.rows_per_batch;
+                const bool full = i + 1 < MI && vec_ok && mblk + 32 <= g.M &&
+                                  (mblk + 31) / g.rows_per_batch == bb;
+                if (full) {
+                    const u32x2 x = __builtin_bit_cast(u32x2, oh[i]);
+                    const u32x2 y = __builtin_bit_cast(u32x2, oh[i + 1 < MI ? i + 1 : i]);
+                    unsigned x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+                    swap16(x0, y0);
+                    swap16(x1, y1);
+                    const int ml = mblk - bb * g.rows_per_batch + prow;
+                    if (n_ok)
+                        *reinterpret_cast<u32x4*>(T + (size_t)z * g.strideC + (size_t)bb * g.strideT +
+                                                  (size_t)n * g.ldt + ml) = u32x4{x0, x1, y0, y1};
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (i + u >= MI) continue;
+                        const int mb = mblk + u * 16 + fq * 4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = mb + r;
+                            if (m >= g.M || !n_ok) continue;
+                            const int b = m / g.rows_per_batch, ml = m - b * g.rows_per_batch;
+                            T[(size_t)z * g.strideC + (size_t)b * g.strideT + (size_t)n * g.ldt + ml] =
+                                oh[i + u < MI ? i + u : i][r];
+                        }
+                    }
                 }
             }
+        }
         return;
     }
     const bool geglu = g.act == FD_ACT_GEGLU;
