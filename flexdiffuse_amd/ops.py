@@ -280,7 +280,7 @@ def attention_accepts_prescaled(head_dim: int) -> bool:
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, heads: int, n_q: int,
               n_k: int, head_dim: int, causal: bool = False, q_prescaled: bool = False) -> torch.Tensor:
     '''q [B*n_q][C], k [B*n_k][C], vt [B][C][ldvt] -> [B*n_q][C] fp16.  q_prescaled: q already
-    carries head_dim^-0.5 * log2(e) (see QK_LOG2_SCALE / prep_linear(..., scale=)).'''
+    carries head_dim^-0.5 * QK_LOG2E (the UNet folds it into the q projection weights).'''
     out = _empty((B * n_q, heads * head_dim), torch.float16, q)
     d = fd_attention_desc()
     d.Q, d.K, d.Vt, d.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()

@@ -55,8 +55,9 @@ class _Attn:
         d = wq.shape[0] // heads
         self.q_pre = ops.attention_accepts_prescaled(d)
         qs = ops.QK_LOG2E * d ** -0.5 if self.q_pre else 1.0
-        self.q1 = ops.prep_linear(wq.float() * qs, None, dev)
-        self.k1 = ops.prep_linear(g(f'{tb}.attn1.to_k.weight'), None, dev)
+        # self-attention q and k share their input: one GEMM with the weights stacked along N
+        self.qk1 = ops.prep_linear(torch.cat([wq.float() * qs, g(f'{tb}.attn1.to_k.weight').float()], 0),
+                                   None, dev)
         self.v1 = ops.prep_linear(g(f'{tb}.attn1.to_v.weight'), None, dev)
         self.o1 = ops.prep_linear(g(f'{tb}.attn1.to_out.0.weight'), g(f'{tb}.attn1.to_out.0.bias'), dev)
         self.q2 = ops.prep_linear(g(f'{tb}.attn2.to_q.weight').float() * qs, None, dev)
@@ -65,7 +66,7 @@ class _Attn:
         self.o2 = ops.prep_linear(g(f'{tb}.attn2.to_out.0.weight'), g(f'{tb}.attn2.to_out.0.bias'), dev)
         self.ff1 = ops.prep_geglu(g(f'{tb}.ff.net.0.proj.weight'), g(f'{tb}.ff.net.0.proj.bias'), dev)
         self.ff2 = ops.prep_linear(g(f'{tb}.ff.net.2.weight'), g(f'{tb}.ff.net.2.bias'), dev)
-        self.C = self.q1.N
+        self.C = self.q2.N
         self.ctx_kv = None  # (K [Be*L][C], V^T [Be][C][ldv]) of the cached text context
 
 
@@ -190,7 +191,8 @@ class UNet2DConditionModel():
         h = ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False)
         h = ops.gemm(h.t, a.proj_in)
         n = ops.layernorm(h, *a.ln[0])
-        q, k = ops.gemm(n, a.q1), ops.gemm(n, a.k1)
+        qk = ops.gemm(n, a.qk1)
+        q, k = qk[:, :C], qk[:, C:]
         vt = ops.gemm_vt(n, a.v1, B, HW, (HW + 7) // 8 * 8)
         o = ops.attention(q, k, vt, B, a.heads, HW, HW, d, q_prescaled=a.q_pre)
         h = ops.gemm(o, a.o1, residual=h)
