@@ -190,6 +190,18 @@ def main():
         achieved = (g['work'] / (g['ms'] * 1e-3)) / 1e12 if g['ms'] > 0 else 0.0
         att = fam['attention']
         gn = fam['groupnorm']
+        # HBM bytes of the dominant kernel (level-0 conv3x3) from its PMC pass: rocprofv3 cannot
+        # run inside this process, so the committed per-launch measurement is reported
+        traffic, traffic_of = None, None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                                   'r01_pmc_traffic.json')) as f:
+                tj = json.load(f)
+            traffic = tj['hbm_bytes']
+            traffic_of = (f"{tj['problem']}: {tj['hbm_bytes'] / 1e6:.1f} MB per launch vs "
+                          f"{tj['algorithmic_bytes'] / 1e6:.1f} MB algorithmic (profiles/r01_pmc_traffic.json)")
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             'metric': '512x512 50-step images/sec/node (SD1.5, batch=8/GPU, Linear image guidance)',
             'value': value, 'unit': 'images/sec', 'n_gpus': N, 'steps': args.steps,
@@ -203,7 +215,7 @@ def main():
             'roofline': {
                 'bound': 'mfma', 'kernel': 'k_gemm_f16 (implicit-GEMM conv3x3 / GEMM family)',
                 'achieved': achieved, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / MFMA_PEAK_TFLOPS, 'traffic': None,
+                'frac': achieved / MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_of': traffic_of,
                 'launches': g['launches'], 'kernel_ms_per_pass': g['ms'],
                 'attention_tflops': (att['work'] / (att['ms'] * 1e-3)) / 1e12 if att['ms'] else 0.0,
                 'attention_ms_per_pass': att['ms'],

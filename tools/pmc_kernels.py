@@ -3,6 +3,11 @@ import torch
 from flexdiffuse_amd import ops
 dev = torch.device('cuda:0')
 only = sys.argv[1] if len(sys.argv) > 1 else ''
+if only == 'conv':
+    x = ops.Act(torch.randn((16*64*64,320), device=dev).half(), 16,64,64)
+    w = ops.prep_conv(torch.randn((320,320,3,3))*(9*320)**-0.5, torch.randn(320), dev)
+    for _ in range(3): ops.conv2d(x, w)
+    torch.cuda.synchronize(); sys.exit(0)
 if only == 'attn':
     for (B,N,heads,d) in [(16,4096,8,40),(16,1024,8,80)]:
         C=heads*d
