@@ -48,6 +48,83 @@ def synthetic_state_dicts(preset: str = 'sd15', seed: int = 0, branch_gain: floa
     return out
 
 
+# newer diffusers checkpoints name the VAE mid-block attention like the UNet's; the containers
+# use the diffusers 0.3.0 names the reference was written against
+_VAE_ATTN_ALIASES = (('.to_q.', '.query.'), ('.to_k.', '.key.'), ('.to_v.', '.value.'),
+                     ('.to_out.0.', '.proj_attn.'))
+_IGNORED_KEYS = ('position_ids',)   # buffers some transformers versions serialise
+
+
+def _read_safetensors(path: str) -> Dict[str, torch.Tensor]:
+    from safetensors import safe_open
+    out = {}
+    with safe_open(path, framework='pt', device='cpu') as f:
+        for k in f.keys():
+            out[k] = f.get_tensor(k)
+    return out
+
+
+def _fit(sd: Dict[str, torch.Tensor], shapes, what: str) -> Dict[str, torch.Tensor]:
+    '''Check a loaded state dict against the architecture's parameter table (names AND shapes;
+    a checkpoint of another architecture must fail loudly, not produce noise images).'''
+    got = {}
+    for k, v in sd.items():
+        if k.endswith(_IGNORED_KEYS):
+            continue
+        for a, b in _VAE_ATTN_ALIASES:
+            if what == 'vae' and a in k:
+                k = k.replace(a, b)
+        if what == 'vae' and k.endswith('.weight') and v.dim() == 4 and k in shapes and len(shapes[k]) == 2:
+            v = v.reshape(v.shape[0], v.shape[1])       # 1x1-conv form of the attention projections
+        got[k] = v
+    missing = [k for k in shapes if k not in got]
+    unexpected = [k for k in got if k not in shapes]
+    bad = [(k, tuple(got[k].shape), tuple(shapes[k])) for k in shapes
+           if k in got and tuple(got[k].shape) != tuple(shapes[k])]
+    if missing or unexpected or bad:
+        raise ValueError(f'{what} checkpoint does not match the architecture: {len(missing)} missing '
+                         f'(e.g. {missing[:3]}), {len(unexpected)} unexpected (e.g. {unexpected[:3]}), '
+                         f'{len(bad)} wrong shape (e.g. {bad[:3]})')
+    return {k: got[k].float() for k in shapes}
+
+
+def load_state_dicts(sd_dir: str, clip_dir: str, preset: str = 'sd15') -> Dict[str, dict]:
+    '''Real weights from a local diffusers-layout directory and a CLIPModel directory -- what
+    the reference's `Runner.__init__` downloads (utils.py:24-25, 59-68: "CompVis/stable-
+    diffusion-v1-4" and "openai/clip-vit-large-patch14"); there is no network here, so the
+    files must already be on disk.  `sd_dir` holds unet/ and vae/ with
+    diffusion_pytorch_model.safetensors, `clip_dir` holds model.safetensors of the full
+    CLIPModel (text + vision tower + projections).  Returns the same {'unet','vae','clip'}
+    dict of fp32 CPU tensors as `synthetic_state_dicts`, validated name-by-name and
+    shape-by-shape against the preset's architecture.'''
+    import os
+    ucfg, vcfg, ccfg = configs(preset)
+
+    def find(d, names):
+        for n in names:
+            if os.path.exists(os.path.join(d, n)):
+                return os.path.join(d, n)
+        raise FileNotFoundError(f'none of {names} under {d}')
+
+    st = ('diffusion_pytorch_model.safetensors', 'diffusion_pytorch_model.fp16.safetensors')
+    return {
+        'unet': _fit(_read_safetensors(find(os.path.join(sd_dir, 'unet'), st)),
+                     W.unet_param_shapes(ucfg), 'unet'),
+        'vae': _fit(_read_safetensors(find(os.path.join(sd_dir, 'vae'), st)),
+                    W.vae_param_shapes(vcfg), 'vae'),
+        'clip': _fit(_read_safetensors(find(clip_dir, ('model.safetensors',))),
+                     W.clip_param_shapes(ccfg), 'clip'),
+    }
+
+
+def load_tokenizer(tokenizer_dir: str):
+    '''The real BPE tokenizer (vocab.json + merges.txt on disk) through transformers; the
+    containers only need `__call__(..., padding, max_length, truncation, return_tensors)` and
+    `model_max_length` (encode/clip.py:57-63).'''
+    from transformers import CLIPTokenizer
+    return CLIPTokenizer.from_pretrained(tokenizer_dir, local_files_only=True)
+
+
 def configs(preset: str):
     ucfg, vcfg, ccfg = PRESETS[preset]
     if preset.startswith('mini'):
@@ -56,15 +133,16 @@ def configs(preset: str):
 
 
 def build_models(state_dicts: Dict[str, dict], preset: str = 'sd15', device='cuda',
-                 vae_encoder: bool = True, steps_offset: int = 0):
-    '''(pipeline, clip, tokenizer): device containers + FlexPipeline around them.'''
+                 vae_encoder: bool = True, steps_offset: int = 0, tokenizer=None):
+    '''(pipeline, clip, tokenizer): device containers + FlexPipeline around them.  `tokenizer`:
+    e.g. `load_tokenizer(dir)`; default is the synthetic one (no vocabulary ships here).'''
     from .pipeline.flex import FlexPipeline
     ucfg, vcfg, ccfg = configs(preset)
     unet = UNet2DConditionModel(state_dicts['unet'], ucfg, device)
     vae = AutoencoderKL(state_dicts['vae'], vcfg, device, encoder=vae_encoder)
     clip = CLIPModel(state_dicts['clip'], ccfg, device)
-    tok = SyntheticTokenizer(vocab_size=ccfg.text.vocab_size,
-                             model_max_length=ccfg.text.max_position_embeddings)
+    tok = tokenizer or SyntheticTokenizer(vocab_size=ccfg.text.vocab_size,
+                                          model_max_length=ccfg.text.max_position_embeddings)
     sched = DDIMScheduler(steps_offset=steps_offset, prediction_type=ucfg.prediction_type)
     pipe = FlexPipeline(vae, clip, tok, unet, sched).to(device)
     return pipe, clip, tok

@@ -33,3 +33,41 @@ def test_synth_weights_deterministic():
     k = 'text_model.encoder.layers.0.mlp.fc1.weight'
     assert torch.equal(a[k], b[k]) and not torch.equal(a[k], c[k])
     assert a['text_model.encoder.layers.0.layer_norm1.weight'].mean().item() > 0.8
+
+
+def test_load_state_dicts_from_safetensors(tmp_path):
+    '''Checkpoint loading: a diffusers-layout directory written with
+    safetensors round-trips through build.load_state_dicts, including the newer VAE attention
+    key names and 1x1-conv attention weights; a wrong architecture fails loudly.'''
+    import os
+    import pytest
+    import torch
+    from safetensors.torch import save_file
+    from flexdiffuse_amd import build
+    sds = build.synthetic_state_dicts('mini', seed=3)
+    sd_dir, clip_dir = tmp_path / 'sd', tmp_path / 'clip'
+    for sub in ('unet', 'vae'):
+        os.makedirs(sd_dir / sub)
+    os.makedirs(clip_dir)
+    save_file({k: v.contiguous() for k, v in sds['unet'].items()},
+              str(sd_dir / 'unet' / 'diffusion_pytorch_model.safetensors'))
+    vae = {}
+    for k, v in sds['vae'].items():          # write the VAE in the newer naming / conv form
+        for old, new in (('.query.', '.to_q.'), ('.key.', '.to_k.'), ('.value.', '.to_v.'),
+                         ('.proj_attn.', '.to_out.0.')):
+            if old in k:
+                k = k.replace(old, new)
+                if k.endswith('.weight'):
+                    v = v.reshape(*v.shape, 1, 1)
+        vae[k] = v.contiguous()
+    save_file(vae, str(sd_dir / 'vae' / 'diffusion_pytorch_model.safetensors'))
+    clip = {k: v.contiguous() for k, v in sds['clip'].items()}
+    clip['text_model.embeddings.position_ids'] = torch.arange(8).unsqueeze(0)
+    save_file(clip, str(clip_dir / 'model.safetensors'))
+    got = build.load_state_dicts(str(sd_dir), str(clip_dir), 'mini')
+    for part in ('unet', 'vae', 'clip'):
+        assert list(got[part]) == list(sds[part])
+        for k in sds[part]:
+            assert torch.equal(got[part][k], sds[part][k]), (part, k)
+    with pytest.raises(ValueError, match='does not match the architecture'):
+        build.load_state_dicts(str(sd_dir), str(clip_dir), 'sd15')
