@@ -16,5 +16,5 @@ FlexPipeline = _flex.FlexPipeline
 from .pipeline.guide import GuideBase, PromptGuide, SimpleGuide  # noqa: E402,F401
 from .scheduler import DDIMScheduler, LMSDiscreteScheduler, PNDMScheduler  # noqa: E402,F401
 from .tokenizer import SyntheticTokenizer  # noqa: E402,F401
-from .build import build_models, synthetic_state_dicts  # noqa: E402,F401
+from .build import build_models, load_state_dicts, load_tokenizer, synthetic_state_dicts  # noqa: E402,F401
 from .utils import Runner, image_grid  # noqa: E402,F401
