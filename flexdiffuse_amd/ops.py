@@ -278,10 +278,14 @@ def attention_accepts_prescaled(head_dim: int) -> bool:
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, heads: int, n_q: int,
-              n_k: int, head_dim: int, causal: bool = False, q_prescaled: bool = False) -> torch.Tensor:
-    '''q [B*n_q][C], k [B*n_k][C], vt [B][C][ldvt] -> [B*n_q][C] fp16.  q_prescaled: q already
-    carries head_dim^-0.5 * QK_LOG2E (the UNet folds it into the q projection weights).'''
-    out = _empty((B * n_q, heads * head_dim), torch.float16, q)
+              n_k: int, head_dim: int, causal: bool = False, q_prescaled: bool = False,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    '''q [B*n_q][C], k [B*n_k][C], vt [B][C][ldvt] -> [B*n_q][C] fp16 (into `out` if given).
+    q_prescaled: q already carries head_dim^-0.5 * QK_LOG2E (the UNet folds it into the q
+    projection weights).'''
+    if out is None:
+        out = _empty((B * n_q, heads * head_dim), torch.float16, q)
+    assert out.shape == (B * n_q, heads * head_dim) and out.dtype == torch.float16
     d = fd_attention_desc()
     d.Q, d.K, d.Vt, d.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
     d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(0), k.stride(0), vt.stride(1), out.stride(0)

@@ -185,7 +185,11 @@ class UNet2DConditionModel():
         sc = x.t if r.short is None else ops.gemm(x.t, r.short)
         return ops.conv2d(h, r.conv2, residual=sc)
 
-    def _attn(self, a: _Attn, x: Act) -> Act:
+    def _attn(self, a: _Attn, x: Act, rep: int = 1) -> Act:
+        '''Transformer block.  rep > 1: `x` holds B samples that are shared by `rep` branches of
+        the cached context (CFG: [uncond]*B + cond on the same latents).  Everything up to the
+        cross-attention query is branch-independent and computed once; the output has rep*B
+        samples.'''
         B, HW, C = x.B, x.HW, a.C
         d = C // a.heads
         h = ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False)
@@ -198,11 +202,20 @@ class UNet2DConditionModel():
         h = ops.gemm(o, a.o1, residual=h)
         n = ops.layernorm(h, *a.ln[1])
         kc, vtc, L = a.ctx_kv
-        o = ops.attention(ops.gemm(n, a.q2), kc, vtc, B, a.heads, HW, L, d, q_prescaled=a.q_pre)
+        xt = x.t
+        if rep == 1:
+            o = ops.attention(ops.gemm(n, a.q2), kc, vtc, B, a.heads, HW, L, d, q_prescaled=a.q_pre)
+        else:
+            q2 = ops.gemm(n, a.q2)
+            o = torch.empty((rep * B * HW, C), dtype=torch.float16, device=q2.device)
+            for r in range(rep):
+                ops.attention(q2, kc[r * B * L:(r + 1) * B * L], vtc[r * B:(r + 1) * B], B, a.heads,
+                              HW, L, d, q_prescaled=a.q_pre, out=o[r * B * HW:(r + 1) * B * HW])
+            h, xt, B = h.repeat(rep, 1), xt.repeat(rep, 1), rep * B
         h = ops.gemm(o, a.o2, residual=h)
         n = ops.layernorm(h, *a.ln[2])
         h = ops.gemm(ops.gemm(n, a.ff1, act=ops.ACT_GEGLU), a.ff2, residual=h)
-        return Act(ops.gemm(h, a.proj_out, residual=x.t), B, x.H, x.W)
+        return Act(ops.gemm(h, a.proj_out, residual=xt), B, x.H, x.W)
 
     # ---- forward ----------------------------------------------------------------------------
     def time_bias(self, timestep, B: int) -> torch.Tensor:
@@ -225,17 +238,26 @@ class UNet2DConditionModel():
         noise prediction as NHWC fp32 [rep*B*h*w][4].'''
         hip.require_device(sample, ctx)
         self.set_context(ctx)
-        x = ops.nchw_to_nhwc(sample, rep=rep, c_pad=self.conv_in.cin)
-        if ctx.shape[0] != x.B:
-            raise ValueError(f'encoder_hidden_states batch {ctx.shape[0]} != latent batch {x.B}')
-        temb = self.time_bias(timestep, x.B)
+        # The `rep` branches see the same latents and timestep, so everything before the first
+        # cross-attention (conv_in, the first ResBlock, the first block's self-attention) is
+        # computed once on B samples and fanned out there (bit-identical per sample).
+        share = rep > 1 and not isinstance(timestep, torch.Tensor)
+        x = ops.nchw_to_nhwc(sample, rep=1 if share else rep, c_pad=self.conv_in.cin)
+        Be = x.B * (rep if share else 1)
+        if ctx.shape[0] != Be:
+            raise ValueError(f'encoder_hidden_states batch {ctx.shape[0]} != latent batch {Be}')
+        temb = self.time_bias(timestep, Be)
         h = ops.conv2d(x, self.conv_in)
-        skips = [h]
+        fan = rep if share else 1      # > 1 while h still holds the shared B samples
+        skips = [Act(h.t.repeat(fan, 1), Be, h.H, h.W) if fan > 1 else h]
         for blk in self.down:
             for r, a in zip(blk['res'], blk['attn']):
-                h = self._res(r, h, temb)
+                h = self._res(r, h, temb[:h.B])
                 if a is not None:
-                    h = self._attn(a, h)
+                    h = self._attn(a, h, fan)
+                elif fan > 1:
+                    h = Act(h.t.repeat(fan, 1), Be, h.H, h.W)
+                fan = 1
                 skips.append(h)
             if blk['down'] is not None:
                 h = ops.conv2d(h, blk['down'], stride=2)
