@@ -113,6 +113,25 @@ def test_unet_forward_vs_oracle(mini, dev):
         assert e < 3e-2, (t, e)
 
 
+def test_unet_cfg_prefix_sharing_matches_replicated_batch(mini, dev):
+    '''forward_nhwc(rep=2) computes conv_in, the first ResBlock and the first self-attention once
+    for both CFG branches; it must equal the plain forward of the replicated batch (oracle
+    semantics of pipeline/guide.py:46-58: latents duplicated, one UNet call).'''
+    from oracle import unet_ref
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = mini
+    g = torch.Generator().manual_seed(5)
+    B, h = 3, 16
+    x = torch.randn((B, 4, h, h), generator=g)
+    ctx = torch.randn((2 * B, 77, ucfg.cross_attention_dim), generator=g).half().float()
+    shared = pipe.unet.forward_nhwc(x.to(dev), 437, ctx.to(dev), rep=2)
+    plain = pipe.unet.forward_nhwc(torch.cat([x, x]).to(dev), 437, ctx.to(dev), rep=1)
+    assert shared.shape == plain.shape == (2 * B * h * h, 4)
+    assert float((shared - plain).abs().max()) <= 1e-3 * float(plain.abs().max())
+    want = unet_ref.unet_forward(sds['unet'], ucfg, torch.cat([x, x]), 437, ctx)
+    got = shared.view(2 * B, h, h, 4).permute(0, 3, 1, 2)
+    assert relerr(got, want) < 3e-2
+
+
 def test_vae_decode_encode_vs_oracle(mini, dev):
     from oracle import vae_ref
     sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = mini
