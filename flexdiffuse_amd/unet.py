@@ -241,7 +241,7 @@ class UNet2DConditionModel():
         # The `rep` branches see the same latents and timestep, so everything before the first
         # cross-attention (conv_in, the first ResBlock, the first block's self-attention) is
         # computed once on B samples and fanned out there (bit-identical per sample).
-        share = rep > 1 and not isinstance(timestep, torch.Tensor)
+        share = rep > 1 and (not isinstance(timestep, torch.Tensor) or timestep.numel() == 1)
         x = ops.nchw_to_nhwc(sample, rep=1 if share else rep, c_pad=self.conv_in.cin)
         Be = x.B * (rep if share else 1)
         if ctx.shape[0] != Be:
