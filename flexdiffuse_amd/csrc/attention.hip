@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * NW, (DQK <= 96 ? 2 : 1)) void k_attention(Attn
 #define ATT_VPRE 0
 #endif
 template <int DQK, int DV, bool PRE, bool ONES>
-__global__ __launch_bounds__(512, (DQK <= 96 ? 2 : 1)) void k_attention_w8(AttnArgs a) {
+__global__ __launch_bounds__(512, (DV <= 3 ? 8 : DQK <= 96 ? 2 : 1)) void k_attention_w8(AttnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KS = DQK / 32;
     constexpr int NT = 512;

@@ -20,7 +20,7 @@ def timeit(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/n
 out=[]
-for (B,N,heads,d,Nk) in [(16,4096,8,40,4096),(16,1024,8,80,1024),(16,256,8,160,256),(16,4096,8,40,77),(16,1024,8,80,77)]:
+for (B,N,heads,d,Nk) in [(16,4096,8,40,4096),(8,4096,8,40,4096),(16,1024,8,80,1024),(16,256,8,160,256),(16,4096,8,40,77),(16,1024,8,80,77)]:
     C=heads*d
     q = torch.randn((B*N,C),device=dev).half(); k = torch.randn((B*Nk,C),device=dev).half()
     vt = torch.randn((B,C,(Nk+7)//8*8),device=dev).half()
