@@ -451,3 +451,29 @@ def test_sd15_full_size_unet_properties(sd15, dev):
     ops.cfg_ddim_step(lat, zero, 8, 4, 4096, False, 1.0, c[:4])
     acp = pipe.scheduler.alphas_cumprod
     assert torch.allclose(lat, xd * float(np.sqrt(acp[480] / acp[500])), rtol=1e-5, atol=1e-6)
+
+
+def test_sd21_c5_size_unet_properties(dev):
+    """BASELINE configs[4] sizes: SD2.1-style UNet (context 1024, head dim 64, linear
+    projections, v-prediction) at 96x96 latents (768x768 images), CFG pair of 2 samples.
+    No reference behaviour exists for this config (the reference hard-codes SD-v1-4), so the
+    target is the CPU oracle on one sample plus sample independence at 9216 tokens."""
+    from flexdiffuse_amd import build, ops
+    from flexdiffuse_amd.unet import UNet2DConditionModel
+    from oracle import unet_ref
+    sds = build.synthetic_state_dicts('sd21', seed=0, parts=('unet',))
+    ucfg, _, _ = build.configs('sd21')
+    unet = UNet2DConditionModel(sds['unet'], ucfg, dev)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((2, 4, 96, 96), generator=g)
+    ctx = torch.randn((4, 77, 1024), generator=g).half().float()
+    xd, cd = x.to(dev), ctx.to(dev)
+    eps = unet.forward_nhwc(xd, 321, cd, rep=2)
+    full = ops.nhwc_to_nchw(eps, 4, 4, 96, 96)
+    assert bool(torch.isfinite(full).all())
+    alone = unet(xd[1:2], 321, encoder_hidden_states=cd[3:4]).sample      # sample 1, cond half
+    assert relerr(alone, full[3:4]) < 1e-2
+    want = unet_ref.unet_forward(sds['unet'], ucfg, x[1:2], 321, ctx[3:4])
+    e = relerr(full[3:4], want)
+    print(f'SD2.1-size UNet forward (96x96) vs CPU oracle: rel err {e:.4f}')
+    assert e < 3e-2
