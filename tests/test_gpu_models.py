@@ -477,3 +477,39 @@ def test_sd21_c5_size_unet_properties(dev):
     e = relerr(full[3:4], want)
     print(f'SD2.1-size UNet forward (96x96) vs CPU oracle: rel err {e:.4f}')
     assert e < 3e-2
+
+
+def test_sd15_c4_size_img2img_properties(dev):
+    """BASELINE configs[3] sizes: SD1.5 img2img at 768x768 (96x96 latents), 50 DDIM steps,
+    strength 0.6 => 30 UNet evaluations from timesteps[20:] (pipeline/flex.py:193-221).  Too
+    large for the CPU oracle; checked through size-independent properties: the executed
+    timestep list, output range / shape, and bit-identical reruns from the same generator."""
+    from flexdiffuse_amd import SimpleGuide, build
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    sds = build.synthetic_state_dicts('sd15', seed=0)
+    pipe, clip, tok = build.build_models(sds, 'sd15', dev, vae_encoder=True)
+    enc = CLIPEncoder(clip, tok)
+    g = torch.Generator().manual_seed(6)
+    image = (torch.rand((1, 3, 768, 768), generator=g) * 2 - 1)
+    emb = enc.prompt(['a castle on a hill', 'a bowl of fruit'])
+    seen = []
+    inner = pipe.unet.forward_nhwc
+
+    def spy(sample, t, ctx, rep=1):
+        seen.append(int(t))
+        return inner(sample, t, ctx, rep=rep)
+    pipe.unet.forward_nhwc = spy
+    try:
+        outs = []
+        for _ in range(2):
+            out = pipe(guide=SimpleGuide(enc, pipe.unet, 8.0, 50, emb), init_image=image, strength=0.6,
+                       generator=torch.Generator('cpu').manual_seed(3), output_type='np')
+            outs.append(np.asarray(out.images))
+    finally:
+        pipe.unet.forward_nhwc = inner
+    want_t = [int(t) for t in pipe.scheduler.timesteps[20:]]
+    assert len(want_t) == 30 and seen == want_t + want_t
+    assert outs[0].shape == (2, 768, 768, 3)
+    assert np.isfinite(outs[0]).all() and outs[0].min() >= 0.0 and outs[0].max() <= 1.0
+    assert np.array_equal(outs[0], outs[1])           # deterministic kernels, same generator
+    assert float(np.abs(outs[0][0] - outs[0][1]).mean()) > 1e-3   # the two prompts differ
