@@ -54,7 +54,7 @@ class FlexPipeline():
         self.last_images: Optional[torch.Tensor] = None
         # opt-in: replay the UNet forward of the fused loop from a captured HIP graph (no
         # per-kernel host launch work).  Measured on one MI355X the loop is not launch-bound
-        # (graph 5.91 vs eager 5.94 images/s), so eager launches stay the default.
+        # (graph 7.00 vs eager 7.14 images/s on the same box), so eager launches stay the default.
         self.use_graph = False
         self._graphs = {}
         self._lat_bufs = {}
