@@ -244,7 +244,8 @@ def test_cfg_ddim_and_layout(dev):
 
 
 @pytest.mark.parametrize('tile,split', [(1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (1, 2), (2, 4),
-                                        (5, 2), (6, 4), (3, 8), (7, 1), (8, 1), (7, 2), (9, 1), (10, 2), (12, 1), (13, 1), (13, 4)])
+                                        (5, 2), (6, 4), (3, 8), (7, 1), (8, 1), (7, 2), (9, 1), (10, 2), (12, 1), (13, 1), (13, 4),
+                                        (14, 1), (15, 1), (15, 2), (16, 1), (16, 2)])
 def test_gemm_every_tile_and_split(dev, tile, split):
     """Each block tile (incl. the 8-wave 256-row ones) and split-K factor gives the same
     result as torch on a conv and on a ragged linear problem."""
