@@ -54,6 +54,7 @@ struct GemmArgs {
     int ldt;
     float alpha;
     int tiles_m, tiles_n;
+    int bias_lds;  // stage the tile's bias through LDS (FD_GEMM_BIAS_LDS=0 reads it from global memory)
     int split_k;   // > 1: blockIdx.y owns a K slice and stores fp32 partials to `ws`
     float* ws;     // [split_k][M][N] fp32
 };
@@ -103,7 +104,12 @@ __device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
 template <int BM, int BN, bool TRANS, int WM = 2, int WN = 2>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                                               floatx4 (&acc)[BM / WM / 16][BN / WN / 16], int m0, int n0,
-                                              int wm, int wn, int fr, int fq, int z) {
+                                              int wm, int wn, int fr, int fq, int z,
+                                              const float* bias_tile = nullptr) {
+    // bias_tile: this tile's bias[n0 .. n0+BN) staged in LDS by the main loop's first DMA group
+    // (zeros past N).  A bias read from global memory here is a dependent L2 round trip that
+    // every wave of the workgroup sits out between the last MFMA and the first store
+    // (65536x320x320: 31.9 us with it, 26.4 us without).
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = WTM / 16, NI = WTN / 16;
     // ---- split-K: raw fp32 partial tile, reduced + finished by k_splitk_finish ------------
@@ -140,7 +146,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
         for (int j = 0; j < NI; ++j) {
             const int n = n0 + wn * WTN + j * 16 + fr;
             const bool n_ok = n < g.N;
-            const float bn = (n_ok && g.bias) ? g.bias[n] : 0.f;
+            const float bn = (n_ok && g.bias) ? (bias_tile ? bias_tile[n - n0] : g.bias[n]) : 0.f;
             half4 oh[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -208,9 +214,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                     gt[r] = acc[i][j + 1][r] * g.alpha;
                 }
                 if (g.bias && nb0 + 16 < g.N) {
-                    const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb0);
+                    const float* bp = bias_tile ? bias_tile + (nb0 - n0) : g.bias + nb0;
+                    const float4 bb = *reinterpret_cast<const float4*>(bp);
                     v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                    const float4 bg = *reinterpret_cast<const float4*>(g.bias + nb0 + 16);
+                    const float4 bg = *reinterpret_cast<const float4*>(bp + 16);
                     gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
                 }
 #pragma unroll
@@ -245,7 +252,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
             if (g.bias) {
-                const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb0);
+                const float4 bb = *reinterpret_cast<const float4*>(bias_tile ? bias_tile + (nb0 - n0) : g.bias + nb0);
                 v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
             }
             if (g.bias2) {
@@ -516,6 +523,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
         (void*)(g.A + (size_t)z * g.strideA), 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(g.W + (size_t)z * g.strideW), 0, w_bytes, 0x00020000);
+    // this tile's bias -> LDS (4 B per lane, 64 columns per wave instruction; zeros past N),
+    // ahead of the first K-tile so that it lands with it
+    float* bias_s = reinterpret_cast<float*>(smem + NS * STAGE);
+    if (g.bias && g.bias_lds) {
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)g.bias, 0, (unsigned)((g.N + 3) & ~3) * 4u, 0x00020000);
+        if (wave < (BN + 63) / 64)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(bias_s + wave * 64), 4,
+                                                     (unsigned)(n0 + wave * 64 + lane) * 4u, 0, 0, 0);
+    }
 
     const int rsub = lane >> 3;            // row inside the 8-row group
     const int ck = (lane & 7) ^ rsub;      // source chunk for this lane's LDS slot (swizzle)
@@ -702,7 +719,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
         }
     }
 #undef GEMM_DMA_TILE
-    gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z);
+    gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? bias_s : nullptr);
 #endif
 }
 
@@ -728,6 +745,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
         (void*)(g.A + (size_t)z * g.strideA), 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(g.W + (size_t)z * g.strideW), 0, w_bytes, 0x00020000);
+    // per-tile bias staged in LDS (two buffers: the next tile's bias arrives with its first
+    // K-tile while the current tile's epilogue still reads its own)
+    float* bias_s = reinterpret_cast<float*>(smem + 2 * STAGE);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(g.bias ? g.bias : (const float*)g.W), 0, g.bias ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
+    int bias_par = 0;
+#define GEMM_DMA_BIAS(PAR)                                                                  \
+    if (wave < (BN + 63) / 64)                                                              \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(bias_s + (PAR) * BN + wave * 64), 4, \
+                                                 (unsigned)(ld_n0 + wave * 64 + lane) * 4u, 0, 0, 0);
 
     const int rsub = lane >> 3;            // row inside the 8-row group
     const int ck = (lane & 7) ^ rsub;      // source chunk for this lane's LDS slot (swizzle)
@@ -850,6 +877,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
     int t = blockIdx.x;
     int stage = 0;
     GEMM_SETUP_TILE(t);
+    GEMM_DMA_BIAS(0);
     GEMM_DMA_TILE(kt0, 0);
     floatx4 acc[MI][NI];
 #pragma clang loop unroll(disable)
@@ -870,6 +898,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
                 GEMM_DMA_TILE(kt + 1, cur ^ 1);
             } else if (t_next < nb) {
                 GEMM_SETUP_TILE(t_next);
+                GEMM_DMA_BIAS(bias_par ^ 1);
                 GEMM_DMA_TILE(kt0, cur ^ 1);
             }
             const char* st = smem + cur * STAGE;
@@ -898,11 +927,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
                 __syncthreads();
             }
         }
-        gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z);
+        gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z,
+                                             (g.bias && g.bias_lds) ? bias_s + bias_par * BN : nullptr);
+        bias_par ^= 1;
         t = t_next;
     }
 #undef GEMM_DMA_TILE
 #undef GEMM_SETUP_TILE
+#undef GEMM_DMA_BIAS
 #endif
 }
 
@@ -949,6 +981,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs g) {
 
 // --------------------------------------------------------------------------------------
 static bool g_use_dma = getenv("FD_GEMM_NO_DMA") == nullptr;
+static int g_bias_lds = getenv("FD_GEMM_BIAS_LDS") ? atoi(getenv("FD_GEMM_BIAS_LDS")) : 1;
 // 0 = never, 1 = short-K GEMMs only (default), 2 = always
 static int g_persist_mode = getenv("FD_GEMM_PERSIST") ? atoi(getenv("FD_GEMM_PERSIST")) : 1;
 
@@ -956,7 +989,7 @@ template <int BM, int BN, bool TRANS, bool CONV, int WM = 2, int NS = 2, int WN 
 static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     g.tiles_m = fd_cdiv(g.M, BM);
     g.tiles_n = fd_cdiv(g.N, BN);
-    const size_t lds = NS * (size_t)(BM + BN) * 128;
+    const size_t lds = NS * (size_t)(BM + BN) * 128 + 2 * BN * sizeof(float);   // stages + bias tiles
     dim3 grid(g.tiles_m * g.tiles_n, g.split_k, batch);
     // tensor extents for the buffer descriptors of the LDS-DMA loop (must fit 32 bits)
     const unsigned long long a_bytes =
@@ -1063,6 +1096,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const double flops = 2.0 * (double)d->M * d->N * d->K * batch;
     g.split_k = 1;
+    g.bias_lds = g_bias_lds;
     g.ws = (float*)d->workspace;
     int rc;
     if (d->trans_out) {
@@ -1157,7 +1191,6 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         case 8: rc = launch<256, 128, false, 4, 3>(g, batch, st); break;
         case 15: rc = launch<256, 256, false, 4, 2, 4>(g, batch, st); break;  // 16 waves, 64x64 wave tiles
         case 16: rc = launch<256, 320, false, 4, 2, 4>(g, batch, st); break;  // 16 waves, 64x80 wave tiles
-        case 17: rc = launch<128, 320, false, 2, 2, 5>(g, batch, st); break;  // 10 waves, 64x64 wave tiles
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }
     if (rc == FD_OK && g.split_k > 1) {

@@ -24,7 +24,7 @@ torch.manual_seed(0)
 x = torch.randn(2, 320, 32, 32); w = torch.randn(640, 320, 3, 3) * (9 * 320) ** -0.5; b = torch.randn(640)
 want = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, 640)
 xa = ops.nchw_to_nhwc(x.to(dev)); wp = ops.prep_conv(w, b, dev)
-for t in (13, 15, 16, 17):
+for t in (13, 15, 16):
     ops.FORCE_TILE, ops.FORCE_SPLIT = t, 1
     y = ops.conv2d(xa, wp).t.float().cpu()
     print('conv tile', t, 'max err', float((y - want).abs().max()))
@@ -48,7 +48,7 @@ for t in (0, 14, 15):
     print('tile', t, ' '.join(row))
 print('--- conv3x3 us')
 shapes = [(16,64,320,320),(16,64,640,320),(16,64,960,320),(16,64,640,640),(16,32,640,640),(16,32,1280,640),(16,32,1920,640),(16,32,1280,1280),(16,16,1280,1280),(16,16,2560,1280)]
-for (t, sp) in [(0, 0), (13, 1), (16, 1), (16, 2), (17, 1), (17, 2), (15, 1), (15, 2)]:
+for (t, sp) in [(0, 0), (13, 1), (16, 1), (16, 2), (15, 1), (15, 2)]:
     row = []
     for (B, H, Cin, Cout) in shapes:
         x = ops.Act(torch.randn((B * H * H, Cin), device=dev).half(), B, H, H)
@@ -58,7 +58,7 @@ for (t, sp) in [(0, 0), (13, 1), (16, 1), (16, 2), (17, 1), (17, 2), (15, 1), (1
     print('tile', t, 'split', sp, ' '.join(row))
 print('--- linear (FF out K=4C, proj K=C) us')
 lin = [(65536,320,1280),(16384,640,2560),(4096,1280,5120),(65536,320,320),(16384,640,640)]
-for t in (0, 13, 16, 17, 15):
+for t in (0, 13, 16, 15):
     row = []
     for (M, N, K) in lin:
         a = torch.randn((M, K), device=dev).half(); w = ops.prep_linear(torch.randn((N, K)) * K ** -0.5, torch.randn(N), dev)
