@@ -88,6 +88,7 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     }
 }
 
+typedef const __attribute__((address_space(3))) float* lds_cfloat;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs
 
@@ -105,11 +106,17 @@ template <int BM, int BN, bool TRANS, int WM = 2, int WN = 2>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                                               floatx4 (&acc)[BM / WM / 16][BN / WN / 16], int m0, int n0,
                                               int wm, int wn, int fr, int fq, int z,
-                                              const float* bias_tile = nullptr) {
+                                              lds_cfloat bias_tile = nullptr, lds_cfloat bias2_tile = nullptr) {
     // bias_tile: this tile's bias[n0 .. n0+BN) staged in LDS by the main loop's first DMA group
     // (zeros past N).  A bias read from global memory here is a dependent L2 round trip that
     // every wave of the workgroup sits out between the last MFMA and the first store
-    // (65536x320x320: 31.9 us with it, 26.4 us without).
+    // (65536x320x320: 31.9 us with it, 26.4 us without).  The pointers are LDS-typed on purpose:
+    // a `cond ? lds : global` pointer turns the read into a FLAT load that the compiler brackets
+    // with s_waitcnt vmcnt(0) -- a full drain of the in-flight LDS-DMA and stores per fragment.
+    // bias2_tile: the same for the per-sample bias when the whole tile lies in one sample.
+    // Loads that must come from global memory (residual, per-sample bias of multi-sample tiles)
+    // are issued as one batch per 16-row block: hipcc drains the VM counter before the first use
+    // of any VGPR-destination load while an LDS-DMA is in flight, so one wait serves them all.
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = WTM / 16, NI = WTN / 16;
     // ---- split-K: raw fp32 partial tile, reduced + finished by k_splitk_finish ------------
@@ -146,7 +153,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
         for (int j = 0; j < NI; ++j) {
             const int n = n0 + wn * WTN + j * 16 + fr;
             const bool n_ok = n < g.N;
-            const float bn = (n_ok && g.bias) ? (bias_tile ? bias_tile[n - n0] : g.bias[n]) : 0.f;
+            float bn = 0.f;
+            if (n_ok && g.bias) {
+                if (bias_tile) bn = bias_tile[n - n0];
+                else bn = g.bias[n];
+            }
             half4 oh[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -214,11 +225,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                     gt[r] = acc[i][j + 1][r] * g.alpha;
                 }
                 if (g.bias && nb0 + 16 < g.N) {
-                    const float* bp = bias_tile ? bias_tile + (nb0 - n0) : g.bias + nb0;
-                    const float4 bb = *reinterpret_cast<const float4*>(bp);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                    const float4 bg = *reinterpret_cast<const float4*>(bp + 16);
-                    gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
+                    floatx4 bb, bg;
+                    if (bias_tile) {
+                        bb = *reinterpret_cast<const __attribute__((address_space(3))) floatx4*>(bias_tile + (nb0 - n0));
+                        bg = *reinterpret_cast<const __attribute__((address_space(3))) floatx4*>(bias_tile + (nb0 - n0) + 16);
+                    } else {
+                        bb = *reinterpret_cast<const floatx4*>(g.bias + nb0);
+                        bg = *reinterpret_cast<const floatx4*>(g.bias + nb0 + 16);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] += bb[r];
+                        gt[r] += bg[r];
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) og[jp][r] = (half_t)(v[r] * gelu_fast(gt[r]));
@@ -244,6 +263,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
             continue;
         }
         half4 oh[NI];
+        // global-memory operands of this row block, issued together (see the header comment)
+        constexpr bool BATCH = MI * NI < 16;   // the 64-row wave tiles have no registers to spare
+        half4 rres[BATCH ? NI : 1];
+        floatx4 rb2[BATCH ? NI : 1];
+        const bool b2_global = g.bias2 && !bias2_tile;
+        if constexpr (BATCH) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int nb0 = n0 + wn * WTN + j * 16 + fq * 4;
+                rres[j] = half4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+                rb2[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (nb0 >= g.N) continue;
+                if (g.res)
+                    rres[j] = *reinterpret_cast<const half4*>(g.res + (size_t)z * g.strideRes + (size_t)m * g.ldr + nb0);
+                if (b2_global) rb2[j] = *reinterpret_cast<const floatx4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int nb0 = n0 + wn * WTN + j * 16 + fq * 4;
@@ -252,19 +288,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
             if (g.bias) {
-                const float4 bb = *reinterpret_cast<const float4*>(bias_tile ? bias_tile + (nb0 - n0) : g.bias + nb0);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                floatx4 bb;
+                if (bias_tile) bb = *reinterpret_cast<const __attribute__((address_space(3))) floatx4*>(bias_tile + (nb0 - n0));
+                else bb = *reinterpret_cast<const floatx4*>(g.bias + nb0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bb[r];
             }
             if (g.bias2) {
-                const float4 bb =
-                    *reinterpret_cast<const float4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                floatx4 bb;
+                if (bias2_tile) bb = *reinterpret_cast<const __attribute__((address_space(3))) floatx4*>(bias2_tile + (nb0 - n0));
+                else if constexpr (BATCH) bb = rb2[j];
+                else bb = *reinterpret_cast<const floatx4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bb[r];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], g.act);
             if (g.res) {
-                const half4 rr = *reinterpret_cast<const half4*>(
-                    g.res + (size_t)z * g.strideRes + (size_t)m * g.ldr + nb0);
+                half4 rr;
+                if constexpr (BATCH) rr = rres[j];
+                else rr = *reinterpret_cast<const half4*>(g.res + (size_t)z * g.strideRes + (size_t)m * g.ldr + nb0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
             }
@@ -529,8 +572,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     if (g.bias && g.bias_lds) {
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
             (void*)g.bias, 0, (unsigned)((g.N + 3) & ~3) * 4u, 0x00020000);
-        if (wave < (BN + 63) / 64)
+        if (wave * 64 + lane < BN)   // lanes past the tile would spill into the next LDS buffer
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(bias_s + wave * 64), 4,
+                                                     (unsigned)(n0 + wave * 64 + lane) * 4u, 0, 0, 0);
+    }
+    // per-sample bias (ResBlock time embedding): one row when the whole tile lies in one sample
+    const int b_first = m0 / g.rows_per_batch;
+    const bool b2_staged = g.bias2 && g.bias_lds && (min(m0 + BM, g.M) - 1) / g.rows_per_batch == b_first;
+    if (b2_staged) {
+        const __amdgpu_buffer_rsrc_t rsB2 = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(g.bias2 + (size_t)b_first * g.ldb2), 0, (unsigned)((g.N + 3) & ~3) * 4u, 0x00020000);
+        if (wave * 64 + lane < BN)   // lanes past the tile would spill into the next LDS buffer
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(bias_s + BN + wave * 64), 4,
                                                      (unsigned)(n0 + wave * 64 + lane) * 4u, 0, 0, 0);
     }
 
@@ -719,7 +772,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
         }
     }
 #undef GEMM_DMA_TILE
-    gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? bias_s : nullptr);
+    gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
+                                         b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr);
 #endif
 }
 
@@ -752,7 +806,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
         (void*)(g.bias ? g.bias : (const float*)g.W), 0, g.bias ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
     int bias_par = 0;
 #define GEMM_DMA_BIAS(PAR)                                                                  \
-    if (wave < (BN + 63) / 64)                                                              \
+    if (wave * 64 + lane < BN)                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(bias_s + (PAR) * BN + wave * 64), 4, \
                                                  (unsigned)(ld_n0 + wave * 64 + lane) * 4u, 0, 0, 0);
 
@@ -880,6 +934,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
     GEMM_DMA_BIAS(0);
     GEMM_DMA_TILE(kt0, 0);
     floatx4 acc[MI][NI];
+#define GEMM_MFMA_TILE(ST)                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                      \
+        const int sw = ks ? sw1 : sw0;                                                      \
+        half8 fa[MI], fb[NI];                                                               \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                      \
+            fa[i] = *reinterpret_cast<const half8*>((ST) + frag_a + i * 2048 + sw);         \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j)                                      \
+            fb[j] = *reinterpret_cast<const half8*>((ST) + frag_b + j * 2048 + sw);         \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                      \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                  \
+                acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(                 \
+                                        fa[i], fb[j], acc[i][j], 0, 0, 0)                   \
+                                  : __builtin_amdgcn_mfma_f32_16x16x32_f16(                 \
+                                        fb[j], fa[i], acc[i][j], 0, 0, 0);                  \
+    }
 #pragma clang loop unroll(disable)
     while (t < nb) {
         const int m0 = ld_m0, n0 = ld_n0;
@@ -902,25 +971,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
                 GEMM_DMA_TILE(kt0, cur ^ 1);
             }
             const char* st = smem + cur * STAGE;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int sw = ks ? sw1 : sw0;
-                half8 fa[MI], fb[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    fa[i] = *reinterpret_cast<const half8*>(st + frag_a + i * 2048 + sw);
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    fb[j] = *reinterpret_cast<const half8*>(st + frag_b + j * 2048 + sw);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                                fa[i], fb[j], acc[i][j], 0, 0, 0)
-                                          : __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                                fb[j], fa[i], acc[i][j], 0, 0, 0);
-            }
+            GEMM_MFMA_TILE(st);
             stage ^= 1;
             if (!last) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -928,10 +979,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
             }
         }
         gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z,
-                                             (g.bias && g.bias_lds) ? bias_s + bias_par * BN : nullptr);
+                                             (g.bias && g.bias_lds) ? (lds_cfloat)(bias_s + bias_par * BN) : (lds_cfloat) nullptr);
         bias_par ^= 1;
         t = t_next;
     }
+#undef GEMM_MFMA_TILE
 #undef GEMM_DMA_TILE
 #undef GEMM_SETUP_TILE
 #undef GEMM_DMA_BIAS

@@ -265,3 +265,31 @@ def test_gemm_every_tile_and_split(dev, tile, split):
         close(out[:, :N], F.silu(a @ wl.T + bl), rtol=3e-3, atol=3e-3)
     finally:
         ops.FORCE_TILE, ops.FORCE_SPLIT = 0, 0
+
+
+def test_gemm_bias_tiles_staged_in_lds(dev):
+    """The DMA kernels stage each tile's bias (and the per-sample bias of single-sample tiles)
+    in LDS.  Tile widths that are not a multiple of 64 (160) must not let the last 64-column
+    slice spill into the neighbouring buffer: distinct bias values per column, several n-tiles,
+    a per-sample bias, persistent and one-shot launches, bit-identical reruns."""
+    from flexdiffuse_amd import ops
+    B, cin, cout, H = 3, 64, 480, 16                      # 3 n-tiles of 160; tiles lie inside one sample
+    x, w = rnd((B, cin, H, H), 1), rnd((cout, cin, 3, 3), 2, (9 * cin) ** -0.5)
+    b = torch.arange(cout, dtype=torch.float32) * 0.25 - 40.0
+    b2 = rnd((B, cout), 3) * 8.0
+    xa, wp = ops.nchw_to_nhwc(x.to(dev)), ops.prep_conv(w, b, dev)
+    b2d = b2.to(dev).contiguous()
+    want = (F.conv2d(x, w, b, padding=1) + b2[:, :, None, None]).permute(0, 2, 3, 1).reshape(B * H * H, cout)
+    outs = [ops.conv2d(xa, wp, bias2=b2d, ld_bias2=cout).t.float().cpu() for _ in range(4)]
+    close(outs[0], want, rtol=3e-3, atol=2e-2)
+    assert all(torch.equal(outs[0], o) for o in outs)
+    # short-K linear with many tiles (persistent kernel: the next tile's bias arrives while the
+    # current epilogue reads its own)
+    M, N, K = 8192, 800, 320                               # 5 n-tiles of 160
+    a, wl = rnd((M, K), 5), rnd((N, K), 6, K ** -0.5)
+    bl = torch.arange(N, dtype=torch.float32) * 0.125 - 50.0
+    wlp = ops.prep_linear(wl, bl, dev)
+    ad = a.half().to(dev)
+    outs = [ops.gemm(ad, wlp).float().cpu() for _ in range(4)]
+    close(outs[0][:, :N], a.half().float() @ wl.half().float().T + bl, rtol=3e-3, atol=3e-2)
+    assert all(torch.equal(outs[0], o) for o in outs)
