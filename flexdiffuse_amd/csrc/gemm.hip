@@ -54,6 +54,7 @@ struct GemmArgs {
     int ldt;
     float alpha;
     int tiles_m, tiles_n;
+    int tap_fast;  // conv: tap-fastest K order (see k_gemm_f16_dma)
     int bias_lds;  // stage the tile's bias through LDS (FD_GEMM_BIAS_LDS=0 reads it from global memory)
     int split_k;   // > 1: blockIdx.y owns a K slice and stores fp32 partials to `ws`
     float* ws;     // [split_k][M][N] fp32
@@ -627,16 +628,28 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     const int ktail = g.K - ck * 8;
     int kh = 0, kw = 0, ci0 = 0;
     bool new_tap = true;
+    // tap_fast: K-tiles visit all filter taps of one 64-channel slice before the next slice
+    // (the nine taps re-read the same input rows, so the re-use distance in the XCD's L2 drops
+    // from Cin/64 K-tiles to one); the W K-offset follows, the sum is only re-ordered
+    const int ntaps = CONV ? g.K / g.Cin : 1;
     if (CONV && kt0 > 0) {
-        const int tap = (kt0 * BK) / g.Cin;
-        ci0 = kt0 * BK - tap * g.Cin;
-        kh = tap / g.KW;
-        kw = tap - kh * g.KW;
+        if (g.tap_fast) {
+            const int tap = kt0 % ntaps;
+            ci0 = (kt0 / ntaps) * BK;
+            kh = tap / g.KW;
+            kw = tap - kh * g.KW;
+        } else {
+            const int tap = (kt0 * BK) / g.Cin;
+            ci0 = kt0 * BK - tap * g.Cin;
+            kh = tap / g.KW;
+            kw = tap - kh * g.KW;
+        }
     }
 
 #define GEMM_DMA_TILE(KT, BUF)                                                              \
     {                                                                                       \
         char* stage = smem + (BUF) * STAGE;                                                 \
+        const int wko = CONV ? ((kh * g.KW + kw) * g.Cin + ci0) * 2 : (KT) * BK * 2;        \
         if (CONV) {                                                                         \
             if (new_tap) {                                                                  \
                 _Pragma("unroll") for (int i = 0; i < AR; ++i) {                            \
@@ -657,13 +670,26 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
                 if (AG % NW == 0 || i * NW + wave < AG)                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
                     rsA, (lds_ptr)(stage + (i * NW + wave) * 1024), 16, a_voff[i], soff, 0, 0); \
-            ci0 += BK;                                                                      \
-            if (ci0 >= g.Cin) {                                                             \
-                ci0 = 0;                                                                    \
+            if (g.tap_fast) {                                                               \
                 new_tap = true;                                                             \
                 if (++kw == g.KW) {                                                         \
                     kw = 0;                                                                 \
-                    ++kh;                                                                   \
+                    if ((kh + 1) * g.KW == ntaps) {                                         \
+                        kh = 0;                                                             \
+                        ci0 += BK;                                                          \
+                    } else {                                                                \
+                        ++kh;                                                               \
+                    }                                                                       \
+                }                                                                           \
+            } else {                                                                        \
+                ci0 += BK;                                                                  \
+                if (ci0 >= g.Cin) {                                                         \
+                    ci0 = 0;                                                                \
+                    new_tap = true;                                                         \
+                    if (++kw == g.KW) {                                                     \
+                        kw = 0;                                                             \
+                        ++kh;                                                               \
+                    }                                                                       \
                 }                                                                           \
             }                                                                               \
         } else {                                                                            \
@@ -678,7 +704,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
         {                                                                                   \
             const bool kok = CONV || (KT) * BK < ktail; /* conv: K is a multiple of 64 */   \
             const unsigned bv = kok ? b_voff0 : w_bytes;                                    \
-            const int soff = (KT) * BK * 2;                                                 \
+            const int soff = wko;                                                           \
             _Pragma("unroll") for (int i = 0; i < BR; ++i)                                  \
                 if (BG % NW == 0 || i * NW + wave < BG)                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
@@ -1034,6 +1060,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs g) {
 // --------------------------------------------------------------------------------------
 static bool g_use_dma = getenv("FD_GEMM_NO_DMA") == nullptr;
 static int g_vae15 = getenv("FD_GEMM_VAE15") ? atoi(getenv("FD_GEMM_VAE15")) : 1;
+static int g_tap_fast = getenv("FD_CONV_TAPFAST") ? atoi(getenv("FD_CONV_TAPFAST")) : 1;   // 1: 256x320 tile, 2: every conv tile
 static int g_bias_lds = getenv("FD_GEMM_BIAS_LDS") ? atoi(getenv("FD_GEMM_BIAS_LDS")) : 1;
 // 0 = never, 1 = short-K GEMMs only (default), 2 = always
 static int g_persist_mode = getenv("FD_GEMM_PERSIST") ? atoi(getenv("FD_GEMM_PERSIST")) : 1;
@@ -1232,6 +1259,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                      FD_ESHAPE, "fd_gemm_f16: split_k=%d not possible for this problem", best_split);
     if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7 || best_tile == 9 || best_tile == 12 || best_tile == 13 || best_tile == 16)) best_tile = 1;
     g.split_k = best_split;
+    g.tap_fast = g.mode == MODE_CONV && (g_tap_fast == 2 || (g_tap_fast == 1 && best_tile == 16));
     fd_prof_begin(FD_FAMILY_GEMM, st, flops);
     switch (best_tile) {
         case 2: rc = launch<128, 160, false>(g, batch, st); break;
