@@ -18,7 +18,7 @@
 #define GN_MAX_CHUNKS 256
 
 __global__ void k_gn_stats(const half_t* __restrict__ x, float* __restrict__ part, int HW, int C,
-                           int G, int PL, int pix_per_chunk) {
+                           int G, int PL, int pix_per_chunk, int ldx) {
     extern __shared__ float sm[];  // [PL][C][2]
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int c8 = C >> 3;
@@ -30,14 +30,14 @@ __global__ void k_gn_stats(const half_t* __restrict__ x, float* __restrict__ par
 #pragma unroll
     for (int k = 0; k < 8; ++k) s[k] = q[k] = 0.f;
     if (pl < PL) {
-        const half_t* base = x + ((size_t)b * HW) * C + cc * 8;
+        const half_t* base = x + ((size_t)b * HW) * ldx + cc * 8;   // ldx: row stride of x (>= C)
         int p = p0 + pl;
         // 4 independent 16-byte loads in flight per lane (the kernel is latency-bound otherwise)
         for (; p + 3 * PL < p1; p += 4 * PL) {
             uint4 raw[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                raw[u] = *reinterpret_cast<const uint4*>(base + (size_t)(p + u * PL) * C);
+                raw[u] = *reinterpret_cast<const uint4*>(base + (size_t)(p + u * PL) * ldx);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const half8 v = *reinterpret_cast<const half8*>(&raw[u]);
@@ -50,7 +50,7 @@ __global__ void k_gn_stats(const half_t* __restrict__ x, float* __restrict__ par
             }
         }
         for (; p < p1; p += PL) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(base + (size_t)p * C);
+            const uint4 raw = *reinterpret_cast<const uint4*>(base + (size_t)p * ldx);
             const half8 v = *reinterpret_cast<const half8*>(&raw);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -109,7 +109,7 @@ __device__ __forceinline__ float gn_act(float f, int silu) {
 __global__ void k_gn_apply(const half_t* __restrict__ x, half_t* __restrict__ y,
                            const float* __restrict__ part, const float* __restrict__ gamma,
                            const float* __restrict__ beta, int HW, int C, int G,
-                           int nchunk_stats, int PL, int pix_per_chunk, float eps, int silu) {
+                           int nchunk_stats, int PL, int pix_per_chunk, float eps, int silu, int ldx) {
     extern __shared__ float sm[];   // [2][nsub*G] doubles, then [G][2] floats (mean, rstd)
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int nt = blockDim.x, nsub = nt / G;
@@ -169,14 +169,14 @@ __global__ void k_gn_apply(const half_t* __restrict__ x, half_t* __restrict__ y,
     }
     const int p0 = chunk * pix_per_chunk;
     const int p1 = min(HW, p0 + pix_per_chunk);
-    const half_t* xb = x + ((size_t)b * HW) * C + cc * 8;
+    const half_t* xb = x + ((size_t)b * HW) * ldx + cc * 8;
     half_t* yb = y + ((size_t)b * HW) * C + cc * 8;
     int p = p0 + pl;
     for (; p + 3 * PL < p1; p += 4 * PL) {
         uint4 raw[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            raw[u] = *reinterpret_cast<const uint4*>(xb + (size_t)(p + u * PL) * C);
+            raw[u] = *reinterpret_cast<const uint4*>(xb + (size_t)(p + u * PL) * ldx);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const half8 v = *reinterpret_cast<const half8*>(&raw[u]);
@@ -187,7 +187,7 @@ __global__ void k_gn_apply(const half_t* __restrict__ x, half_t* __restrict__ y,
         }
     }
     for (; p < p1; p += PL) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(xb + (size_t)p * C);
+        const uint4 raw = *reinterpret_cast<const uint4*>(xb + (size_t)p * ldx);
         const half8 v = *reinterpret_cast<const half8*>(&raw);
         half8 o;
 #pragma unroll
@@ -207,7 +207,7 @@ template <int NT, int NV>
 __global__ __launch_bounds__(NT) void k_gn_slab(const half_t* __restrict__ x, half_t* __restrict__ y,
                                                 const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, int HW, int C,
-                                                int G, int GB, float eps, int silu) {
+                                                int G, int GB, float eps, int silu, int ldx) {
     extern __shared__ float sm[];
     const int cpg = C / G, CB = cpg * GB, c8 = CB >> 3;
     const int PL = NT / c8;
@@ -219,9 +219,10 @@ __global__ __launch_bounds__(NT) void k_gn_slab(const half_t* __restrict__ x, ha
     const int cc = tid % c8, pl = tid / c8;
     const bool active = pl < PL;
     // uniform 64-bit base + 32-bit per-lane offsets (keeps the address math out of VGPR pairs)
-    const half_t* xb = x + (size_t)b * HW * C + ch0;
+    const half_t* xb = x + (size_t)b * HW * ldx + ch0;
     half_t* yb = y + (size_t)b * HW * C + ch0;
     const unsigned off0 = (unsigned)(pl * C + cc * 8), ostep = (unsigned)(PL * C);
+    const unsigned xoff0 = (unsigned)(pl * ldx + cc * 8), xstep = (unsigned)(PL * ldx);
     // statistics per channel PAIR with v_dot2_f32_f16 (packed fp16 in, fp32 accumulate): cpg is
     // even (checked by the launcher), so a pair never straddles two groups
     uint4 v[NV];
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(NT) void k_gn_slab(const half_t* __restrict__ x, ha
     for (int i = 0; i < NV; ++i) {
         const int p = pl + PL * i;
         v[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (active && p < HW) v[i] = *reinterpret_cast<const uint4*>(xb + (off0 + ostep * i));
+        if (active && p < HW) v[i] = *reinterpret_cast<const uint4*>(xb + (xoff0 + xstep * i));
     }
     const half2v one2 = {(half_t)1.0f, (half_t)1.0f};
 #pragma unroll
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(NT) void k_gn_slab(const half_t* __restrict__ x, ha
 
 template <int NT, int NV>
 static bool gn_try_slab(const void* x, void* y, const float* gamma, const float* beta, int B,
-                        int HW, int C, int G, float eps, int silu, hipStream_t st, int* rc) {
+                        int HW, int C, int G, float eps, int silu, hipStream_t st, int* rc, int ldx) {
     const int cpg = C / G;
     if (cpg & 1) return false;
     for (int GB = 1; GB <= 8 && GB <= G; GB *= 2) {
@@ -340,7 +341,7 @@ static bool gn_try_slab(const void* x, void* y, const float* gamma, const float*
         }
         fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 4.0);
         hipLaunchKernelGGL((k_gn_slab<NT, NV>), dim3(G / GB, B), dim3(NT), lds, st, (const half_t*)x,
-                           (half_t*)y, gamma, beta, HW, C, G, GB, eps, silu);
+                           (half_t*)y, gamma, beta, HW, C, G, GB, eps, silu, ldx);
         fd_prof_end(FD_FAMILY_GROUPNORM, st);
         *rc = hipGetLastError() == hipSuccess ? FD_OK : FD_EHIP;
         if (*rc != FD_OK) fd_set_error("k_gn_slab: launch failed");
@@ -356,6 +357,15 @@ extern "C" int64_t fd_groupnorm_workspace_floats(int B, int G) {
 extern "C" int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma,
                                      const float* beta, float* ws, int B, int HW, int C, int G,
                                      float eps, int silu, void* stream) {
+    return fd_groupnorm_nhwc_ld_f16(x, C, y, gamma, beta, ws, B, HW, C, G, eps, silu, stream);
+}
+
+extern "C" int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const float* gamma,
+                                        const float* beta, float* ws, int B, int HW, int C, int G,
+                                        float eps, int silu, void* stream) {
+    FD_CHECK_ARG(ldx >= C && ldx % 8 == 0 && (uintptr_t)x % 16 == 0, FD_ESHAPE,
+                 "fd_groupnorm_nhwc_ld_f16: ldx=%d must be >= C=%d, a multiple of 8, x 16-byte aligned", ldx, C);
+    FD_CHECK_ARG((long long)B * HW * ldx < 0x7fffffffLL, FD_ESHAPE, "fd_groupnorm_nhwc_ld_f16: tensor too large");
     FD_CHECK_ARG(x && y && gamma && beta && ws, FD_EINVAL, "fd_groupnorm_nhwc_f16: null pointer");
     FD_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0, FD_EINVAL, "fd_groupnorm_nhwc_f16: bad dims");
     FD_CHECK_ARG(C % 8 == 0 && C % G == 0 && G <= 64, FD_ESHAPE,
@@ -369,10 +379,10 @@ extern "C" int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma,
         const char* e = getenv("FD_GN_NO_SMALL");
         const int off = e ? atoi(e) : 0;
         int rc = FD_OK;
-        if (off != 1 && gn_try_slab<256, 16>(x, y, gamma, beta, B, HW, C, G, eps, silu, st, &rc)) return rc;
+        if (off != 1 && gn_try_slab<256, 16>(x, y, gamma, beta, B, HW, C, G, eps, silu, st, &rc, ldx)) return rc;
         // 1024-thread slabs pay off up to 32x32 maps; at 64x64 the 80-byte rows of a narrow slab
         // waste cache lines and the two streaming passes below are as fast or faster (measured)
-        if (off == 0 && HW <= 1024 && gn_try_slab<1024, 22>(x, y, gamma, beta, B, HW, C, G, eps, silu, st, &rc)) return rc;
+        if (off == 0 && HW <= 1024 && gn_try_slab<1024, 22>(x, y, gamma, beta, B, HW, C, G, eps, silu, st, &rc, ldx)) return rc;
     }
     int PL = 512 / c8;
     if (PL < 1) PL = 1;
@@ -389,10 +399,10 @@ extern "C" int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma,
     const double bytes = (double)B * HW * C * 6.0;
     fd_prof_begin(FD_FAMILY_GROUPNORM, st, bytes);
     hipLaunchKernelGGL(k_gn_stats, dim3(nchunk, B), dim3(threads), lds1, st, (const half_t*)x, ws,
-                       HW, C, G, PL, ppc);
+                       HW, C, G, PL, ppc, ldx);
     const size_t lds2 = (size_t)2 * threads * sizeof(double) + (size_t)2 * G * sizeof(float);
     hipLaunchKernelGGL(k_gn_apply, dim3(nchunk, B), dim3(threads), lds2, st, (const half_t*)x,
-                       (half_t*)y, (const float*)ws, gamma, beta, HW, C, G, nchunk, PL, ppc, eps, silu);
+                       (half_t*)y, (const float*)ws, gamma, beta, HW, C, G, nchunk, PL, ppc, eps, silu, ldx);
     fd_prof_end(FD_FAMILY_GROUPNORM, st);
     FD_CHECK_LAUNCH("k_gn_stats/k_gn_apply");
     return FD_OK;

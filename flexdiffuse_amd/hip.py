@@ -45,6 +45,7 @@ _SIGNATURES = {
     'fd_attention_f16': (c_int, [P, P]),
     'fd_groupnorm_workspace_floats': (c_int64, [c_int, c_int]),
     'fd_groupnorm_nhwc_f16': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    'fd_groupnorm_nhwc_ld_f16': (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'fd_layernorm_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'fd_softmax_rows_f16': (c_int, [P, c_int, c_int, c_int, c_float, P]),
     'fd_nchw_f32_to_nhwc_f16': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),

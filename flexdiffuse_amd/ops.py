@@ -232,7 +232,7 @@ def bgemm(a: torch.Tensor, w: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
 def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), up: bool = False,
            out_hw: Optional[Tuple[int, int]] = None, act: int = ACT_NONE,
            residual: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None,
-           ld_bias2: int = 0, out_f32: bool = False) -> Act:
+           ld_bias2: int = 0, out_f32: bool = False, out: Optional[torch.Tensor] = None) -> Act:
     '''NHWC conv (kh x kw) as implicit GEMM; `up` fuses a nearest-2x upsample of the input.'''
     assert x.C == w.cin, (x.C, w.cin)
     Hv, Wv = (x.H * 2, x.W * 2) if up else (x.H, x.W)
@@ -242,7 +242,10 @@ def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), 
     else:
         Ho, Wo = out_hw
     M = x.B * Ho * Wo
-    out = _empty((M, _round_up(w.cout, 4)), torch.float32 if out_f32 else torch.float16, x.t)
+    if out is None:
+        out = _empty((M, _round_up(w.cout, 4)), torch.float32 if out_f32 else torch.float16, x.t)
+    assert out.shape == (M, _round_up(w.cout, 4)) and out.stride(1) == 1
+    assert x.t.is_contiguous(), 'conv input must be a contiguous NHWC matrix'
     d = fd_gemm_desc()
     d.W, d.C = w.w.data_ptr(), out.data_ptr()
     d.bias, d.bias2, d.residual = _p(w.bias), _p(bias2), _p(residual)
@@ -313,10 +316,11 @@ def _gn_workspace(B: int, G: int, dev) -> torch.Tensor:
 
 def groupnorm(x: Act, gamma: torch.Tensor, beta: torch.Tensor, G: int, eps: float,
               silu: bool) -> Act:
-    out = torch.empty_like(x.t)
-    assert x.t.is_contiguous()
+    # x may be a column slice of a wider matrix (a skip tensor living in its concat buffer)
+    assert x.t.stride(1) == 1
+    out = _empty(tuple(x.t.shape), torch.float16, x.t)
     ws = _gn_workspace(x.B, G, x.t.device)
-    hip.call('fd_groupnorm_nhwc_f16', x.t.data_ptr(), out.data_ptr(), gamma.data_ptr(),
+    hip.call('fd_groupnorm_nhwc_ld_f16', x.t.data_ptr(), x.t.stride(0), out.data_ptr(), gamma.data_ptr(),
              beta.data_ptr(), ws.data_ptr(), x.B, x.HW, x.C, G, eps, int(silu), hip.stream())
     return Act(out, x.B, x.H, x.W)
 

@@ -140,6 +140,32 @@ class UNet2DConditionModel():
         self._attn_layers = [a for blk in self.down for a in blk['attn'] if a] + [self.mid_attn] + \
                             [a for blk in self.up for a in blk['attn'] if a]
         self._ctx_key = None
+        self._cat_plan = self._plan_concats()
+
+    def _plan_concats(self) -> List[Optional[int]]:
+        '''The decoder concatenates its running tensor h (Ch channels) with the encoder skips
+        (diffusers' torch.cat in the up blocks).  Instead of copying both halves, every skip is
+        written by its producer straight into the right-hand columns of a [M][Ch + Cs] buffer and
+        the decoder op that produces h writes the left-hand columns.  Returns, per skip in
+        encoder order, the Ch of the decoder tensor it will meet -- or None for the skips that
+        feed a downsample conv (the conv loader wants a contiguous NHWC input).'''
+        skip_c, excluded = [self.conv_in.cout], set()
+        for blk in self.down:
+            for r in blk['res']:
+                skip_c.append(r.cout)
+            if blk['down'] is not None:
+                excluded.add(len(skip_c) - 1)          # input of the downsample conv
+                skip_c.append(blk['down'].cout)
+        plan: List[Optional[int]] = [None] * len(skip_c)
+        c, i = self.mid_res1.cout, len(skip_c) - 1
+        for blk in self.up:
+            for r in blk['res']:
+                if i not in excluded and r.conv1.cin == c + skip_c[i] and c % 8 == 0 and skip_c[i] % 8 == 0:
+                    plan[i] = c
+                c, i = r.cout, i - 1
+            if blk['up'] is not None:
+                c = blk['up'].cout
+        return plan
 
     # ---- reference surface --------------------------------------------------------------
     def set_attention_slice(self, slice_size):
@@ -177,15 +203,15 @@ class UNet2DConditionModel():
         self._ctx_ref = ctx  # keep the tensor alive so its data_ptr cannot be recycled
 
     # ---- blocks -----------------------------------------------------------------------------
-    def _res(self, r: _Res, x: Act, temb: torch.Tensor) -> Act:
+    def _res(self, r: _Res, x: Act, temb: torch.Tensor, out: Optional[torch.Tensor] = None) -> Act:
         h = ops.groupnorm(x, r.n1g, r.n1b, self.G, 1e-5, True)
         h = ops.conv2d(h, r.conv1, bias2=temb[:, r.temb_off:r.temb_off + r.cout],
                        ld_bias2=self.temb_total)
         h = ops.groupnorm(h, r.n2g, r.n2b, self.G, 1e-5, True)
         sc = x.t if r.short is None else ops.gemm(x.t, r.short)
-        return ops.conv2d(h, r.conv2, residual=sc)
+        return ops.conv2d(h, r.conv2, residual=sc, out=out)
 
-    def _attn(self, a: _Attn, x: Act, rep: int = 1) -> Act:
+    def _attn(self, a: _Attn, x: Act, rep: int = 1, out: Optional[torch.Tensor] = None) -> Act:
         '''Transformer block.  rep > 1: `x` holds B samples that are shared by `rep` branches of
         the cached context (CFG: [uncond]*B + cond on the same latents).  Everything up to the
         cross-attention query is branch-independent and computed once; the output has rep*B
@@ -215,7 +241,7 @@ class UNet2DConditionModel():
         h = ops.gemm(o, a.o2, residual=h)
         n = ops.layernorm(h, *a.ln[2])
         h = ops.gemm(ops.gemm(n, a.ff1, act=ops.ACT_GEGLU), a.ff2, residual=h)
-        return Act(ops.gemm(h, a.proj_out, residual=xt), B, x.H, x.W)
+        return Act(ops.gemm(h, a.proj_out, residual=xt, out=out), B, x.H, x.W)
 
     # ---- forward ----------------------------------------------------------------------------
     def time_bias(self, timestep, B: int) -> torch.Tensor:
@@ -247,33 +273,85 @@ class UNet2DConditionModel():
         if ctx.shape[0] != Be:
             raise ValueError(f'encoder_hidden_states batch {ctx.shape[0]} != latent batch {Be}')
         temb = self.time_bias(timestep, Be)
-        h = ops.conv2d(x, self.conv_in)
         fan = rep if share else 1      # > 1 while h still holds the shared B samples
-        skips = [Act(h.t.repeat(fan, 1), Be, h.H, h.W) if fan > 1 else h]
+        plan = self._cat_plan
+        skips: List[tuple] = []        # (Act of the skip, its concat buffer or None, Ch)
+
+        def slot(rows: int, cs: int):
+            '''Right-hand view of a fresh concat buffer for the next skip (None: plain tensor).'''
+            ch = plan[len(skips)] if len(skips) < len(plan) else None
+            if ch is None:
+                return None, None, None
+            buf = torch.empty((rows, ch + cs), dtype=torch.float16, device=self.device)
+            return buf, buf[:, ch:], ch
+
+        def push(act: Act, buf, ch):
+            skips.append((act, buf, ch))
+            return act
+
+        def left(rows: int, c: int):
+            '''Left-hand view of the buffer the next concat will use, for the op producing h.'''
+            if skips and skips[-1][1] is not None and skips[-1][2] == c and skips[-1][1].shape[0] == rows:
+                return skips[-1][1][:, :c]
+            return None
+
+        HW = x.H * x.W
+        buf, view, ch = slot(Be * HW, self.conv_in.cout)
+        if fan > 1:
+            h = ops.conv2d(x, self.conv_in)
+            if view is None:
+                push(Act(h.t.repeat(fan, 1), Be, h.H, h.W), None, None)
+            else:
+                for f in range(fan):
+                    view[f * x.B * HW:(f + 1) * x.B * HW].copy_(h.t)
+                push(Act(view, Be, h.H, h.W), buf, ch)
+        else:
+            h = push(ops.conv2d(x, self.conv_in, out=view), buf, ch)
         for blk in self.down:
             for r, a in zip(blk['res'], blk['attn']):
-                h = self._res(r, h, temb[:h.B])
+                rows = Be * h.H * h.W
+                buf, view, ch = slot(rows, r.cout)
                 if a is not None:
-                    h = self._attn(a, h, fan)
+                    h = self._res(r, h, temb[:h.B])
+                    h = self._attn(a, h, fan, out=view)
                 elif fan > 1:
-                    h = Act(h.t.repeat(fan, 1), Be, h.H, h.W)
+                    h = self._res(r, h, temb[:h.B])
+                    if view is None:
+                        h = Act(h.t.repeat(fan, 1), Be, h.H, h.W)
+                    else:
+                        for f in range(fan):
+                            view[f * h.B * h.HW:(f + 1) * h.B * h.HW].copy_(h.t)
+                        h = Act(view, Be, h.H, h.W)
+                else:
+                    h = self._res(r, h, temb[:h.B], out=view)
                 fan = 1
-                skips.append(h)
+                push(h, buf, ch)
             if blk['down'] is not None:
-                h = ops.conv2d(h, blk['down'], stride=2)
-                skips.append(h)
+                buf, view, ch = slot(Be * (h.H // 2) * (h.W // 2), blk['down'].cout)
+                h = push(ops.conv2d(h, blk['down'], stride=2, out=view), buf, ch)
         h = self._res(self.mid_res0, h, temb)
         h = self._attn(self.mid_attn, h)
-        h = self._res(self.mid_res1, h, temb)
+        h = self._res(self.mid_res1, h, temb, out=left(h.B * h.HW, self.mid_res1.cout))
         for blk in self.up:
-            for r, a in zip(blk['res'], blk['attn']):
-                s = skips.pop()
-                h = Act(ops.concat_channels(h.t, s.t), h.B, h.H, h.W)
-                h = self._res(r, h, temb)
+            n = len(blk['res'])
+            for j, (r, a) in enumerate(zip(blk['res'], blk['attn'])):
+                s, sbuf, sch = skips.pop()
+                if sbuf is not None and h.t.data_ptr() == sbuf.data_ptr() and h.C == sch:
+                    h = Act(sbuf, h.B, h.H, h.W)          # both halves are already in place
+                else:
+                    h = Act(ops.concat_channels(h.t.contiguous(), s.t.contiguous()), h.B, h.H, h.W)
+                # where the result of this sub-block goes: the next concat's left half, unless an
+                # upsample conv (contiguous input) follows
+                last = j == n - 1
+                dst = None if (last and blk['up'] is not None) else left(h.B * h.HW, r.cout)
                 if a is not None:
-                    h = self._attn(a, h)
+                    h = self._res(r, h, temb)
+                    h = self._attn(a, h, out=dst)
+                else:
+                    h = self._res(r, h, temb, out=dst)
             if blk['up'] is not None:
-                h = ops.conv2d(h, blk['up'], up=True)
+                h = ops.conv2d(h, blk['up'], up=True,
+                               out=left(h.B * h.HW * 4, blk['up'].cout))
         h = ops.groupnorm(h, self.out_g, self.out_b, self.G, 1e-5, True)
         return ops.conv2d(h, self.conv_out, out_f32=True).t
 

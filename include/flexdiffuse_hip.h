@@ -180,6 +180,13 @@ int64_t fd_groupnorm_workspace_floats(int B, int G);
 int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma, const float* beta,
                           float* ws, int B, int HW, int C, int G, float eps, int silu,
                           void* stream);
+/* Same with a row stride ldx >= C (in elements) on the INPUT: x is a column slice of a wider
+ * [B*HW][ldx] matrix (the UNet writes skip tensors straight into the decoder's concatenation
+ * buffers, pipeline/flex.py's UNet call -> diffusers' torch.cat of the skip connections). y is
+ * contiguous [B][HW][C] and must not alias x. */
+int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const float* gamma, const float* beta,
+                             float* ws, int B, int HW, int C, int G, float eps, int silu,
+                             void* stream);
 /* LayerNorm over the last dim of fp16 x [rows][ldx] -> fp16 (or fp32) y [rows][ldy]. */
 int fd_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int rows,
                      int C, int ldx, int ldy, float eps, int out_f32, void* stream);

@@ -132,6 +132,28 @@ def test_unet_cfg_prefix_sharing_matches_replicated_batch(mini, dev):
     assert relerr(got, want) < 3e-2
 
 
+def test_unet_inplace_skip_concat_equals_copying_concat(mini, dev):
+    '''Skips are written by their producers straight into the decoder's concatenation buffers
+    (strided GroupNorm / GEMM operands, no k_concat).  Same kernels, same arithmetic, only the
+    placement differs: the result must be bit-identical to the copying concatenation, for the
+    plain and the CFG-shared forward.'''
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = mini
+    unet = pipe.unet
+    plan = unet._cat_plan
+    assert sum(c is not None for c in plan) >= len(plan) - sum(b['down'] is not None for b in unet.down)
+    g = torch.Generator().manual_seed(9)
+    B, h = 2, 16
+    x = torch.randn((B, 4, h, h), generator=g).to(dev)
+    ctx = torch.randn((2 * B, 77, ucfg.cross_attention_dim), generator=g).half().float().to(dev)
+    got = [unet.forward_nhwc(x, 311, ctx, rep=2).clone(), unet.forward_nhwc(torch.cat([x, x]), 311, ctx).clone()]
+    try:
+        unet._cat_plan = [None] * len(plan)
+        want = [unet.forward_nhwc(x, 311, ctx, rep=2).clone(), unet.forward_nhwc(torch.cat([x, x]), 311, ctx).clone()]
+    finally:
+        unet._cat_plan = plan
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
 def test_vae_decode_encode_vs_oracle(mini, dev):
     from oracle import vae_ref
     sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = mini
