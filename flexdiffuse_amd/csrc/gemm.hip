@@ -1081,8 +1081,9 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         if (!configured && lds > 64 * 1024) {
             FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV, WM, TRANS, NS, WN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if constexpr (BN != 320)   // the 256x320 tile has no persistent form (it would spill)
+                FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS, WN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
         // Short K loops: persistent workgroups (<= 256 CUs x co-resident workgroups) walk the
@@ -1093,9 +1094,11 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         const bool persistent = NS == 2 && BN != 320 && (g_persist_mode == 2 ||
                                 (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots));
         if (persistent) {
-            dim3 pgrid(g.tiles_m * g.tiles_n > slots ? slots : g.tiles_m * g.tiles_n, g.split_k, batch);
-            hipLaunchKernelGGL((k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS, WN>), pgrid, dim3(64 * WM * WN), lds, st, g,
-                               (unsigned)a_bytes, (unsigned)w_bytes);
+            if constexpr (BN != 320) {
+                dim3 pgrid(g.tiles_m * g.tiles_n > slots ? slots : g.tiles_m * g.tiles_n, g.split_k, batch);
+                hipLaunchKernelGGL((k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS, WN>), pgrid, dim3(64 * WM * WN), lds,
+                                   st, g, (unsigned)a_bytes, (unsigned)w_bytes);
+            }
         } else {
             hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV, WM, TRANS, NS, WN>), grid, dim3(64 * WM * WN), lds, st, g,
                                (unsigned)a_bytes, (unsigned)w_bytes);
