@@ -34,6 +34,7 @@ _SIGNATURES = {
     'fd_last_error': (c_char_p, []),
     'fd_device_info': (c_int, [c_int, P, P, P, P, c_int]),
     'fd_prof_enable': (c_int, [c_int]),
+    'fd_prof_set_stride': (c_int, [c_int]),
     'fd_prof_collect': (c_int, [c_int, P, P, P]),
     'fd_guidance_workspace_floats': (c_int64, [c_int, c_int, c_int]),
     'fd_guidance_map': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -137,6 +138,11 @@ def prof_enable(on: bool):
     global _prof_on
     _prof_on = bool(on)
     call('fd_prof_enable', int(bool(on)))
+
+
+def prof_set_stride(stride: int):
+    '''Sample every `stride`-th launch of each kernel family (1 = every launch).'''
+    call('fd_prof_set_stride', int(stride))
 
 
 def prof_is_on() -> bool:

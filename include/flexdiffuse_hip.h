@@ -46,6 +46,10 @@ int fd_device_info(int device, int* cu_count, int* clock_khz, int64_t* hbm_bytes
 #define FD_FAMILY_ATTENTION 1 /* flash attention MFMA kernel */
 #define FD_FAMILY_GROUPNORM 2 /* GroupNorm(+SiLU) statistics + apply */
 int fd_prof_enable(int on);
+/* Record events around every `stride`-th launch of each family only (default 1 = all): a pair of
+ * event records costs ~6.6 us of stream time, which at one pair per launch is ~10 % of the pass
+ * being measured.  fd_prof_collect then sums over the sampled launches. */
+int fd_prof_set_stride(int stride);
 /* Synchronises the recorded events of `family`, returns summed elapsed ms, declared work
  * (FLOPs for MFMA families, algorithmic bytes for HBM families) and launch count, and
  * forgets those records. Host pointers. */
