@@ -14,6 +14,8 @@ is tested with `is not None`.
 '''
 from __future__ import annotations
 
+import contextlib
+import gc
 import inspect
 from typing import List, Optional, Tuple, Union
 
@@ -26,6 +28,18 @@ from ..scheduler import DDIMScheduler, LMSDiscreteScheduler
 from .guide import GuideBase, SimpleGuide
 
 VAE_SCALE = 0.18215
+
+
+@contextlib.contextmanager
+def _gc_paused():
+    was = gc.isenabled()
+    if was:
+        gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class StableDiffusionPipelineOutput():
@@ -201,40 +215,44 @@ class FlexPipeline():
             buf.copy_(latents)
             latents = buf
         is_lms = isinstance(self.scheduler, LMSDiscreteScheduler)
-        for i, t in enumerate(self.progress_bar(self.scheduler.timesteps[t_start:])):
-            if fused:
-                cfg = guide.classifier_free_guidance
-                if debug:
-                    eps = self.unet.forward_nhwc(latents, int(t), guide.stacked_embeds(),
-                                                 rep=2 if cfg else 1)
+        # The host only has to stay ahead of the device queue.  A generation-2 collection of the
+        # cyclic GC walks every tracked object of the process (~175 k with the SD1.5 weights:
+        # ~40 ms) and drains that queue, so collections wait until the images are decoded.
+        with _gc_paused():
+            for i, t in enumerate(self.progress_bar(self.scheduler.timesteps[t_start:])):
+                if fused:
+                    cfg = guide.classifier_free_guidance
+                    if debug:
+                        eps = self.unet.forward_nhwc(latents, int(t), guide.stacked_embeds(),
+                                                     rep=2 if cfg else 1)
+                    else:
+                        eps = self._unet_eps(latents, int(t), guide.stacked_embeds(), 2 if cfg else 1)
+                    coef = self.scheduler.step_coefficients(int(t))[:4]
+                    if debug:
+                        latents = latents.clone()
+                    ops.cfg_ddim_step(latents, eps, B, C, H * W, cfg, guide.guidance, coef,
+                                      self.scheduler.config['prediction_type'] == 'v_prediction')
                 else:
-                    eps = self._unet_eps(latents, int(t), guide.stacked_embeds(), 2 if cfg else 1)
-                coef = self.scheduler.step_coefficients(int(t))[:4]
-                if debug:
-                    latents = latents.clone()
-                ops.cfg_ddim_step(latents, eps, B, C, H * W, cfg, guide.guidance, coef,
-                                  self.scheduler.config['prediction_type'] == 'v_prediction')
-            else:
-                t_index, model_input = t, latents
-                if is_lms:        # pipeline/flex.py:270-274: continuous-ODE input scaling
-                    t_index = t_start + i
-                    sigma = float(self.scheduler.sigmas[t_index])
-                    model_input = ops.axpby(latents, None, 1.0 / ((sigma ** 2 + 1) ** 0.5), 0.0)
-                noise_pred = guide.noise_pred(model_input, t)
-                latents = self.scheduler.step(noise_pred, t_index, latents,
-                                              **extra_step_kwargs).prev_sample
-            if all_latents is not None:
-                all_latents.append(latents)
-        self.last_latents = latents
+                    t_index, model_input = t, latents
+                    if is_lms:        # pipeline/flex.py:270-274: continuous-ODE input scaling
+                        t_index = t_start + i
+                        sigma = float(self.scheduler.sigmas[t_index])
+                        model_input = ops.axpby(latents, None, 1.0 / ((sigma ** 2 + 1) ** 0.5), 0.0)
+                    noise_pred = guide.noise_pred(model_input, t)
+                    latents = self.scheduler.step(noise_pred, t_index, latents,
+                                                  **extra_step_kwargs).prev_sample
+                if all_latents is not None:
+                    all_latents.append(latents)
+            self.last_latents = latents
 
-        if all_latents:
-            batches = [self._latents_to_image(l, output_type == 'pil') for l in all_latents]
-            if isinstance(batches[0], list):
-                batch_images = [im for ib in batches for im in ib]
+            if all_latents:
+                batches = [self._latents_to_image(l, output_type == 'pil') for l in all_latents]
+                if isinstance(batches[0], list):
+                    batch_images = [im for ib in batches for im in ib]
+                else:
+                    batch_images = np.concatenate(batches, axis=0)
             else:
-                batch_images = np.concatenate(batches, axis=0)
-        else:
-            batch_images = self._latents_to_image(latents, output_type == 'pil')
+                batch_images = self._latents_to_image(latents, output_type == 'pil')
 
         if not return_dict:
             return (batch_images, False)
