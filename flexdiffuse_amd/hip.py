@@ -118,7 +118,16 @@ def ptr(t: Optional[torch.Tensor]) -> c_void_p:
     return c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream() -> c_void_p:
+    '''torch's current stream of the current device as a hipStream_t.  Called once per kernel
+    launch: the raw-handle query is ~8x cheaper than building a torch.cuda.Stream object
+    (a third of the host time of a UNet forward went there).'''
+    if _raw_stream is not None and _raw_device is not None:
+        return c_void_p(_raw_stream(_raw_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
