@@ -388,7 +388,9 @@ extern "C" int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const f
     if (PL < 1) PL = 1;
     if (PL > HW) PL = HW;
     const int threads = ((c8 * PL + 63) / 64) * 64;
-    int nchunk = 1024 / B;
+    // one workgroup per CU: with 4x more (smaller) chunks the statistics pass was latency-bound
+    // (16x4096x320: 36 -> 29 us for the pair; 128/B, 192/B, 384/B ... 4096/B all measured slower)
+    int nchunk = 256 / B;
     if (nchunk < 1) nchunk = 1;
     if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
     int ppc = fd_cdiv(HW, nchunk);
