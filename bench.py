@@ -4,16 +4,28 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+`--gpus N` with N > 1 and no torchrun environment: this process (which never touches the GPU)
+starts N child ranks of itself, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+relays rank 0's JSON line and exits with the worst child status.  Under torchrun the
+environment's WORLD_SIZE must equal --gpus.  Fewer than N visible devices is an error
+(no silent fallback to one GPU).
+
 One "step" = one pass of the whole hot path over one batch per GPU (BASELINE.json
 configs[1]): Guide.embeds (CLIP text + ViT image towers, Linear image guidance tween) ->
 50 DDIM steps of the SD1.5 UNet at 512x512 with classifier-free guidance 8, batch 8 per
 GPU -> VAE decode -> (N > 1) RCCL all-gather of final latents and decoded images.
 Weights are seeded synthetic tensors of the exact SD1.5 / CLIP ViT-L/14 architecture and
 inputs are synthetic (no checkpoints or datasets exist offline).  Prints ONE JSON line.
+
+Other BASELINE configs run through the same entry point (not the headline line):
+    --guidance clustered_threshold          configs[2] guidance parameters (c3)
+    --preset sd21 --size 768                configs[4] SD2.1-size UNet + OpenCLIP ViT-H guide (c5)
 '''
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +37,38 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2516.6          # MI355X dense fp16 MFMA: 256 CU x 2.4 GHz x 4096 FLOP/clk/CU
-FLOPS_PER_IMAGE = 82.84e12         # BASELINE.md sec. 3, config c2 (100 UNet forwards + VAE decode)
+HBM_PEAK_GBPS = 8000.0
+# BASELINE.md sec. 3 / SURVEY App. B: UNet forward GFLOP per sample and VAE decode TFLOP
+UNET_GFLOP = {('sd15', 256): 180.1, ('sd15', 512): 803.3, ('sd15', 768): 2148.1, ('sd21', 768): 2149.1}
+VAE_TFLOP = {256: 0.622, 512: 2.515, 768: 5.754}
+
+# the three guidance parameterisations BASELINE.json names
+GUIDANCE = {
+    'linear': dict(guide_threshold_mult=0.0, guide_clustered=0.0, guide_linear=(0.0, 0.5),
+                   guide_max_guidance=0.5),
+    'clustered_threshold': dict(guide_threshold_floor=0.75, guide_threshold_mult=0.25,
+                                guide_clustered=0.25, guide_linear=(0.0, 0.0),
+                                guide_max_guidance=0.35, guide_header_max=0.0),
+    'defaults': dict(),
+}
+
+# reference guidance stage measured with the reference's own guidance.py / encode/clip.py in the
+# build container (8 host cores, torch 2.10 CPU fp32, random-weight ViT-L/14):
+# the reference source cannot travel to the GPU box, so these are constants.
+REFERENCE_GUIDANCE_STAGE = {
+    'source': 'BASELINE.md sec. 2 (reference guidance.py / encode/clip.py imported in the build '
+              'container, 8 cores)',
+    'tween_ms_per_prompt': 83.0, 'map_emb_image_guide_ms': 109.0, 'clip_image_s': 0.58,
+    'clip_prompt_s': 0.047, 'guide_embeds_s_per_prompt': [0.52, 0.67],
+    'host_syncs_per_tween': 19700,
+}
+
+
+def flops_per_image(preset, size, steps):
+    u, v = UNET_GFLOP.get((preset, size)), VAE_TFLOP.get(size)
+    if u is None or v is None:
+        return None
+    return 2 * steps * u * 1e9 + v * 1e12
 
 
 def synth_image(seed, w, h):
@@ -45,16 +88,15 @@ def synth_prompts(n, seed=1):
     return [' '.join(rng.choice(words, size=int(rng.integers(5, 20)))) for _ in range(n)]
 
 
-def cpu_baseline(sds, cfgs, steps, parity_args=None):
+def cpu_baseline(sds, cfgs, steps, size):
     '''Oracle (torch fp32 restatement of the reference path) timed on the host cores over a
-    bounded sample: one CFG UNet evaluation (2 forwards) of ONE image at 64x64 latents plus
-    one 512x512 VAE decode; extrapolated to steps x UNet + decode per image.  With
-    `parity_args` the same leg also runs the oracle on the BASELINE configs[0] shape and
-    reports the GPU path's PSNR against it (the oracle is the checker, never the product).'''
+    bounded sample: one CFG UNet evaluation (2 forwards) of ONE image plus one VAE decode,
+    extrapolated to steps x UNet + decode per image.'''
     from oracle import unet_ref, vae_ref
     ucfg, vcfg, _ = cfgs
     g = torch.Generator().manual_seed(0)
-    x = torch.randn((2, 4, 64, 64), generator=g)
+    h = size // 8
+    x = torch.randn((2, 4, h, h), generator=g)
     ctx = torch.randn((2, 77, ucfg.cross_attention_dim), generator=g)
     t0 = time.time()
     unet_ref.unet_forward(sds['unet'], ucfg, x, 500, ctx)
@@ -63,15 +105,15 @@ def cpu_baseline(sds, cfgs, steps, parity_args=None):
     vae_ref.vae_decode(sds['vae'], vcfg, x[:1])
     t_vae = time.time() - t0
     per_image = steps * t_unet + t_vae
-    parity = parity_leg(sds, cfgs, *parity_args) if parity_args else None
-    return {'parity': parity, 'value': 1.0 / per_image, 'unit': 'images/sec', 'cores': torch.get_num_threads(),
+    return {'value': 1.0 / per_image, 'unit': 'images/sec', 'cores': torch.get_num_threads(),
             'kind': 'port',
-            'sample': f'1 CFG UNet evaluation (2 forwards, 1 image, 64x64 latents) = {t_unet:.2f} s '
+            'sample': f'1 CFG UNet evaluation (2 forwards, 1 image, {h}x{h} latents) = {t_unet:.2f} s '
                       f'and 1 VAE decode = {t_vae:.2f} s on {torch.get_num_threads()} threads '
-                      f'({os.cpu_count()} cpus); extrapolated to {steps} steps + decode per image'}
+                      f'({os.cpu_count()} cpus); extrapolated to {steps} steps + decode per image',
+            'reference_guidance_stage': REFERENCE_GUIDANCE_STAGE}
 
 
-def parity_leg(sds, cfgs, pipe, enc, tok, steps=10, hw=256, guidance=8.0):
+def parity_c1(sds, cfgs, pipe, enc, tok, steps=10, hw=256, guidance=8.0):
     '''BASELINE configs[0] shape (256x256, 10 DDIM steps, batch 1, CFG 8) on the same SD1.5
     weights: GPU fp16 path vs the CPU fp32 oracle with identical ids and CPU-drawn noise.'''
     from flexdiffuse_amd import SimpleGuide
@@ -97,9 +139,97 @@ def parity_leg(sds, cfgs, pipe, enc, tok, steps=10, hw=256, guidance=8.0):
             'cpu_oracle_seconds': cpu_s, 'tolerance': 'PSNR >= 40 dB'}
 
 
+def parity_c2(sds, cfgs, pipe, guide_ctx, enc):
+    '''BASELINE configs[1] at batch 1 (512x512, 50 DDIM steps, CFG 8, Linear image guidance):
+    the device path (Guide.embeds -> FlexPipeline) against the CPU fp32 oracle's final latents
+    of the same sample, cached in tests/golden/c2_oracle.npz by tests/golden/make_c2_oracle.py
+    (100 fp32 UNet forwards, ~13 min on 8 cores); only the oracle's VAE decode runs here.'''
+    import hashlib
+    path = os.path.join(ROOT, 'tests', 'golden', 'c2_oracle.npz')
+    if not os.path.exists(path):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from make_c2_oracle import C2, c2_inputs
+    from flexdiffuse_amd import SimpleGuide
+    from oracle import pipeline_ref
+    ucfg, vcfg, ccfg = cfgs
+    o = np.load(path)
+    steps, size = int(o['steps'][0]), int(o['size'][0])
+    prompt, img, lat0 = c2_inputs(size)
+    assert hashlib.sha256(lat0.numpy().tobytes()).digest() == o['lat0_sha'].tobytes()
+    embeds = guide_ctx.embeds(prompt=prompt, guide=img, **C2['embeds_kw'])
+    pipe(guide=SimpleGuide(enc, pipe.unet, C2['guidance'], steps, embeds), init_size=(size, size),
+         latents=lat0, output_type='np')
+    lat_ref = torch.from_numpy(o['latents'])
+    img_ref = pipeline_ref.decode_image(sds['vae'], vcfg, lat_ref)
+    emb_ref = torch.from_numpy(o['embeds'])
+    lat = pipe.last_latents.float().cpu()
+    return {'config': f'SD1.5 {size}x{size}, {steps} DDIM steps, batch 1, CFG {C2["guidance"]}, Linear '
+                      f'image guidance (BASELINE configs[1], sample 0)',
+            'psnr_db': pipeline_ref.psnr(pipe.last_images.cpu(), img_ref),
+            'latent_max_abs_err': float((lat - lat_ref).abs().max()),
+            'latent_ref_max_abs': float(lat_ref.abs().max()),
+            'guided_embeds_max_abs_err': float((embeds.float().cpu() - emb_ref).abs().max()),
+            'timesteps_equal': [int(t) for t in o['timesteps']] == [int(t) for t in pipe.scheduler.timesteps],
+            'oracle': 'tests/golden/c2_oracle.npz (oracle output cached by tests/golden/make_c2_oracle.py; '
+                      f'{float(o["cpu_seconds"].sum()):.0f} s on {int(o["threads"][0])} threads)',
+            'tolerance': 'PSNR >= 40 dB'}
+
+
 # sampling stride of the per-launch HIP events: coprime with the launch pattern of a UNet step
 # (220 GEMM, 33 attention, 61 GroupNorm launches), so over 50 steps every shape is visited
 EVENT_STRIDE = 7
+
+
+def best_kernel_leg(dev):
+    '''The level-0 ResBlock conv3x3 (16 x 64 x 64 x 320 -> 320, 120.8 GFLOP, the largest single
+    share of the pass) timed alone: 20 launches between two events on the launch stream.'''
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = ops.Act((torch.randn((16 * 4096, 320), generator=g) * 0.5).half().to(dev), 16, 64, 64)
+    w = ops.prep_conv(torch.randn((320, 320, 3, 3), generator=g) * 0.02, torch.zeros(320), dev)
+    for _ in range(3):
+        ops.conv2d(x, w)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        ops.conv2d(x, w)
+    e1.record()
+    e1.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / n
+    tflops = 2.0 * 65536 * 320 * 2880 / (us * 1e-6) / 1e12
+    return {'kernel': 'level-0 conv3x3 16x64x64x320->320 (implicit GEMM M 65536, N 320, K 2880)',
+            'avg_launch_us': us, 'achieved': tflops, 'frac': tflops / MFMA_PEAK_TFLOPS}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int) -> int:
+    '''Parent of an N-rank run: starts N fresh children BEFORE any GPU call in this process
+    (device_count() does not initialise the GPU), one rank per GPU over RCCL.'''
+    visible = torch.cuda.device_count()
+    share = os.environ.get('FD_BENCH_SHARE_GPU') == '1'   # plumbing test: several ranks on one GPU
+    if visible < n and not (share and visible >= 1):
+        print(f'bench.py: --gpus {n} but only {visible} device(s) visible', file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % visible if share else r),
+                   WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -110,15 +240,25 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='images per GPU')
     ap.add_argument('--ddim-steps', type=int, default=50)
     ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--preset', default='sd15')
+    ap.add_argument('--preset', default='sd15', choices=['sd15', 'sd21', 'mini', 'mini2'])
+    ap.add_argument('--guidance', default='linear', choices=sorted(GUIDANCE))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the UNet from a captured HIP graph')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    env_world = int(os.environ.get('WORLD_SIZE', '1'))
+    if env_world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} does not match WORLD_SIZE={env_world}', file=sys.stderr)
+        sys.exit(2)
+
     import torch.distributed as dist
     from flexdiffuse_amd import dist as fdist
     rank, world, local_rank = fdist.init('nccl')
+    if dist.is_initialized():
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     if world == 1:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local_rank if world > 1 else 0)
@@ -143,16 +283,25 @@ def main():
     # images do not depend on the number of GPUs
     noise = fdist.global_noise(B * N, (4, hw // 8, hw // 8), 1337)[fdist.shard_range(rank, N, B)].to(dev)
     t_setup = time.time() - t_setup
+    gather = {'bytes_per_rank': 0, 'ms': 0.0, 'calls': 0}
 
-    def one_pass():
-        embeds = guide_ctx.embeds(prompt=prompts, guide=guide_img, guide_threshold_mult=0.0,
-                                  guide_clustered=0.0, guide_linear=(0.0, 0.5),
-                                  guide_max_guidance=0.5)
+    def one_pass(time_gather=False):
+        embeds = guide_ctx.embeds(prompt=prompts, guide=guide_img, **GUIDANCE[args.guidance])
         sg = SimpleGuide(enc, pipe.unet, 8.0, args.ddim_steps, embeds)
         out = pipe(guide=sg, init_size=(hw, hw), latents=noise, output_type='np')
         # one RCCL all-gather of the final latents and of the decoded images (identity at N=1)
+        if time_gather:
+            torch.cuda.synchronize()
+            tg = time.time()
         all_latents = fdist.all_gather_samples(pipe.last_latents)
         all_images = fdist.all_gather_samples(pipe.last_images)
+        if time_gather:
+            torch.cuda.synchronize()
+            gather['ms'] += 1e3 * (time.time() - tg)
+            gather['calls'] += 1
+            gather['bytes_per_rank'] = (pipe.last_latents.numel() * pipe.last_latents.element_size()
+                                        + pipe.last_images.numel() * pipe.last_images.element_size())
+        assert all_latents.shape[0] == (B * N if dist.is_initialized() else B)
         return out, all_latents, all_images
 
     def sync():
@@ -161,90 +310,117 @@ def main():
         torch.cuda.synchronize()
 
     for w in range(args.warmup):
-        hip.prof_enable(w == args.warmup - 1)   # fills the event pool outside the timed region
         one_pass()
-        torch.cuda.synchronize()
-        for fam in (ops.FAMILY_GEMM, ops.FAMILY_ATTENTION, ops.FAMILY_GROUPNORM):
-            hip.prof_collect(fam)
-        hip.prof_enable(False)
-
     sync()
     t0 = time.time()
     for k in range(args.steps):
-        if k == args.steps - 1 and not os.environ.get('FD_BENCH_NO_EVENTS'):
-            # HIP events on the launch stream around every EVENT_STRIDE-th launch of each kernel
-            # family during the last timed pass (one pair per launch costs ~10 % of that pass)
-            hip.prof_set_stride(EVENT_STRIDE)
-            hip.prof_enable(True)
         one_pass()
     sync()
     elapsed = time.time() - t0
-    hip.prof_enable(False)
     if dist.is_initialized():
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    fam = {}
-    for name, code in (('gemm', ops.FAMILY_GEMM), ('attention', ops.FAMILY_ATTENTION),
-                       ('groupnorm', ops.FAMILY_GROUPNORM)):
-        ms, work, n = hip.prof_collect(code)
-        fam[name] = {'ms': ms, 'work': work, 'launches': n}
+    # ---- roofline leg: one extra UNTIMED pass with HIP events on the launch stream around every
+    # EVENT_STRIDE-th launch of each kernel family (a pair of event records costs stream time, so
+    # it stays out of `elapsed`); the cost of an empty bracket is measured and subtracted.
+    fam, empty_ms = {}, 0.0
+    if rank == 0:
+        empty_ms = hip.prof_calibrate(256)
+        hip.prof_set_stride(EVENT_STRIDE)
+        hip.prof_enable(True)
+        one_pass(time_gather=True)
+        torch.cuda.synchronize()
+        hip.prof_enable(False)
+        for name, code in (('gemm', ops.FAMILY_GEMM), ('attention', ops.FAMILY_ATTENTION),
+                           ('groupnorm', ops.FAMILY_GROUPNORM)):
+            ms, work, n = hip.prof_collect(code)
+            fam[name] = {'ms': max(ms - n * empty_ms, 0.0), 'raw_ms': ms, 'work': work, 'launches': n}
+    elif dist.is_initialized():
+        one_pass(time_gather=True)       # every rank takes part in the extra pass's all-gather
+        torch.cuda.synchronize()
 
     if rank == 0:
         images = B * N * args.steps
         value = images / elapsed
-        g = fam['gemm']
+        ms_per_step = 1e3 * elapsed / args.steps
+        g, att, gn = fam['gemm'], fam['attention'], fam['groupnorm']
         achieved = (g['work'] / (g['ms'] * 1e-3)) / 1e12 if g['ms'] > 0 else 0.0
-        att = fam['attention']
-        gn = fam['groupnorm']
+        fam_sum = EVENT_STRIDE * (g['ms'] + att['ms'] + gn['ms'])
         # HBM bytes of the dominant kernel (level-0 conv3x3) from its PMC pass: rocprofv3 cannot
-        # run inside this process, so the committed per-launch measurement is reported
+        # run inside this process, so the committed per-launch measurement is reported with its
+        # source (it is NOT re-measured by this run)
         traffic, traffic_of = None, None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                                   'r01_pmc_traffic.json')) as f:
-                tj = json.load(f)
-            traffic = tj['hbm_bytes']
-            traffic_of = (f"{tj['problem']}: {tj['hbm_bytes'] / 1e6:.1f} MB per launch vs "
-                          f"{tj['algorithmic_bytes'] / 1e6:.1f} MB algorithmic (profiles/r01_pmc_traffic.json)")
-        except (OSError, KeyError, ValueError):
-            pass
+        for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            try:
+                with open(os.path.join(ROOT, 'profiles', name)) as f:
+                    tj = json.load(f)
+                traffic = tj['hbm_bytes']
+                traffic_of = (f"{tj['problem']}: {tj['hbm_bytes'] / 1e6:.1f} MB per launch vs "
+                              f"{tj['algorithmic_bytes'] / 1e6:.1f} MB algorithmic; constant from "
+                              f"profiles/{name} (commit {tj.get('commit', 'n/a')}), not measured in this run")
+                break
+            except (OSError, KeyError, ValueError):
+                continue
+        fpi = flops_per_image(args.preset, hw, args.ddim_steps)
+        headline = (args.preset == 'sd15' and hw == 512 and args.ddim_steps == 50
+                    and args.guidance == 'linear' and B == 8)
+        cfg_name = {('sd15', 'linear'): 'BASELINE configs[1]',
+                    ('sd15', 'clustered_threshold'): 'BASELINE configs[2] guidance',
+                    ('sd21', 'linear'): 'BASELINE configs[4]'}.get((args.preset, args.guidance), 'non-headline')
+        model = {'sd15': 'SD1.5', 'sd21': 'SD2.1 + OpenCLIP ViT-H/14 guide'}.get(args.preset, args.preset)
         line = {
-            'metric': '512x512 50-step images/sec/node (SD1.5, batch=8/GPU, Linear image guidance)',
+            'metric': '512x512 50-step images/sec/node (SD1.5, batch=8/GPU, Linear image guidance)'
+                      if headline else f'{hw}x{hw} {args.ddim_steps}-step images/sec/node ({model}, '
+                                       f'batch={B}/GPU, {args.guidance} image guidance)',
             'value': value, 'unit': 'images/sec', 'n_gpus': N, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp16',
             'data': 'synthetic',
-            'config': {'workload': f'SD1.5 {hw}x{hw} {args.ddim_steps}-step DDIM + Linear image '
-                                   f'guidance, CFG 8, batch={B}/GPU (BASELINE configs[1])',
+            'config': {'workload': f'{model} {hw}x{hw} {args.ddim_steps}-step DDIM + {args.guidance} image '
+                                   f'guidance, CFG 8, batch={B}/GPU ({cfg_name})',
                        'images_per_step': B * N, 'parallelism': f'seed-sharded x{N}',
-                       'preset': args.preset},
+                       'preset': args.preset, 'guidance': args.guidance},
+            'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 0,
+            'all_gather': {'bytes_per_rank': gather['bytes_per_rank'],
+                           'ms': gather['ms'] / max(gather['calls'], 1),
+                           'backend': ('RCCL (torch.distributed nccl)' if dist.get_backend() == 'nccl'
+                                       else dist.get_backend()) if dist.is_initialized() else 'none (N=1)'},
             'roofline': {
                 'bound': 'mfma', 'kernel': 'k_gemm_f16 (implicit-GEMM conv3x3 / GEMM family)',
                 'achieved': achieved, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_of': traffic_of,
-                # sums over the sampled launches (every EVENT_STRIDE-th of each family), scaled to
-                # the pass; `achieved` is the ratio of sampled work to sampled time
+                # sums over the sampled launches (every EVENT_STRIDE-th of each family) of one
+                # untimed pass, empty-bracket cost subtracted, scaled to the pass
                 'sampled_every': EVENT_STRIDE, 'sampled_launches': g['launches'],
                 'launches': g['launches'] * EVENT_STRIDE,
+                'empty_bracket_us': 1e3 * empty_ms,
                 'kernel_ms_per_pass': g['ms'] * EVENT_STRIDE,
                 'avg_launch_us': 1e3 * g['ms'] / g['launches'] if g['launches'] else None,
                 'attention_tflops': (att['work'] / (att['ms'] * 1e-3)) / 1e12 if att['ms'] else 0.0,
                 'attention_ms_per_pass': att['ms'] * EVENT_STRIDE,
+                # GroupNorm priced at SURVEY 8(d)'s 4 B/element (fp16 read + write)
                 'groupnorm_gbps': (gn['work'] / (gn['ms'] * 1e-3)) / 1e9 if gn['ms'] else 0.0,
+                'groupnorm_frac_of_hbm': ((gn['work'] / (gn['ms'] * 1e-3)) / 1e9 / HBM_PEAK_GBPS) if gn['ms'] else 0.0,
                 'groupnorm_ms_per_pass': gn['ms'] * EVENT_STRIDE,
+                'families_ms_per_pass': fam_sum,
+                'families_fit_in_step': fam_sum <= ms_per_step,
                 'end_to_end_frac_of_mfma_roofline':
-                    (value / N) * FLOPS_PER_IMAGE / (MFMA_PEAK_TFLOPS * 1e12)
-                    if (hw == 512 and args.ddim_steps == 50 and args.preset == 'sd15') else None,
+                    (value / N) * fpi / (MFMA_PEAK_TFLOPS * 1e12) if fpi else None,
             },
             'device': info, 'setup_s': t_setup,
         }
+        line['roofline']['best_kernel'] = best_kernel_leg(dev)
+        line['roofline']['frac_best_kernel'] = line['roofline']['best_kernel']['frac']
+        if N == 1 and not args.no_parity and args.preset == 'sd15':
+            line['parity'] = {'c1': parity_c1(sds, cfgs, pipe, enc, tok)}
+            c2 = parity_c2(sds, cfgs, pipe, guide_ctx, enc)
+            if c2 is not None:
+                line['parity']['c2'] = c2
         if N == 1 and not args.no_cpu_baseline:
-            sds32 = sds if args.preset != 'sd15' else sds
-            pargs = (pipe, enc, tok) if (not args.no_parity and args.preset == 'sd15') else None
-            line['cpu_baseline'] = cpu_baseline(sds32, cfgs, args.ddim_steps, pargs)
-            line['parity'] = line['cpu_baseline'].pop('parity')
+            line['cpu_baseline'] = cpu_baseline(sds, cfgs, args.ddim_steps, hw)
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -100,6 +100,31 @@ extern "C" int fd_prof_set_stride(int stride) {
     return FD_OK;
 }
 
+// Cost of an EMPTY bracket: `pairs` back-to-back (record, record) pairs on `stream`, mean elapsed
+// ms per pair.  bench.py subtracts it from every sampled launch, so the per-family sums are
+// kernel time rather than kernel time + event-record time (round-1 sums exceeded the wall clock).
+extern "C" int fd_prof_calibrate(int pairs, double* ms_per_empty_pair, void* stream) {
+    FD_CHECK_ARG(pairs >= 1 && pairs <= 4096 && ms_per_empty_pair, FD_EINVAL,
+                 "fd_prof_calibrate: pairs must be in [1, 4096] and the result pointer non-null");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev(2 * (size_t)pairs);
+    for (auto& e : ev) FD_HIP(hipEventCreate(&e));
+    for (int i = 0; i < pairs; ++i) {
+        FD_HIP(hipEventRecord(ev[2 * i], s));
+        FD_HIP(hipEventRecord(ev[2 * i + 1], s));
+    }
+    FD_HIP(hipStreamSynchronize(s));
+    double sum = 0;
+    for (int i = 0; i < pairs; ++i) {
+        float t = 0.f;
+        FD_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+        sum += t;
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    *ms_per_empty_pair = sum / pairs;
+    return FD_OK;
+}
+
 // Sums (after synchronising the recorded events) the elapsed ms, the declared work
 // (FLOPs or bytes) and the launch count of `family`; then forgets those records.
 extern "C" int fd_prof_collect(int family, double* total_ms, double* total_work,

@@ -24,6 +24,10 @@ def world() -> Tuple[int, int, int]:
 
 
 def init(backend: str = 'nccl'):
+    '''Join the process group described by the torchrun environment (no-op for one rank unless
+    FD_FORCE_DIST=1).  FD_DIST_BACKEND overrides the backend (e.g. gloo when several ranks share
+    one GPU in a plumbing test: RCCL refuses duplicate devices).'''
+    backend = os.environ.get('FD_DIST_BACKEND', backend)
     rank, ws, local = world()
     # FD_FORCE_DIST=1 initialises the process group (and runs the collectives through RCCL)
     # even for a single rank: exercises the N > 1 code path on a 1-GPU box
@@ -60,6 +64,10 @@ def all_gather_samples(x: torch.Tensor) -> torch.Tensor:
             (dist.get_world_size() == 1 and not os.environ.get('FD_FORCE_DIST')):
         return x
     x = x.contiguous()
+    if x.is_cuda and dist.get_backend() == 'gloo':
+        # gloo moves host memory: stage through the CPU (test plumbing only; RCCL takes the
+        # device tensors directly over xGMI)
+        return all_gather_samples(x.cpu()).to(x.device)
     out = torch.empty((dist.get_world_size() * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype,
                       device=x.device)
     dist.all_gather_into_tensor(out, x)

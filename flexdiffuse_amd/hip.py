@@ -36,6 +36,7 @@ _SIGNATURES = {
     'fd_prof_enable': (c_int, [c_int]),
     'fd_prof_set_stride': (c_int, [c_int]),
     'fd_prof_collect': (c_int, [c_int, P, P, P]),
+    'fd_prof_calibrate': (c_int, [c_int, P, P]),
     'fd_guidance_workspace_floats': (c_int64, [c_int, c_int, c_int]),
     'fd_guidance_map': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'fd_guidance_tween': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int,
@@ -64,7 +65,7 @@ _SIGNATURES = {
     'fd_cast_f16_to_f32': (c_int, [P, P, c_int64, P]),
 }
 
-ABI_VERSION = 2   # FD_ABI_VERSION in include/flexdiffuse_hip.h
+ABI_VERSION = 3   # FD_ABI_VERSION in include/flexdiffuse_hip.h
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -156,6 +157,13 @@ def prof_set_stride(stride: int):
 
 def prof_is_on() -> bool:
     return _prof_on
+
+
+def prof_calibrate(pairs: int = 256) -> float:
+    '''Mean elapsed ms of an empty event bracket on the current stream.'''
+    ms = c_double(0)
+    call('fd_prof_calibrate', int(pairs), ctypes.byref(ms), stream())
+    return ms.value
 
 
 def prof_collect(family: int):

@@ -32,7 +32,7 @@ extern "C" {
 #define FD_ESHAPE (-2) /* unsupported shape / alignment */
 #define FD_EHIP (-3)   /* HIP runtime error */
 
-#define FD_ABI_VERSION 2
+#define FD_ABI_VERSION 3
 
 int fd_abi_version(void);
 const char* fd_last_error(void);
@@ -54,6 +54,9 @@ int fd_prof_set_stride(int stride);
  * (FLOPs for MFMA families, algorithmic bytes for HBM families) and launch count, and
  * forgets those records. Host pointers. */
 int fd_prof_collect(int family, double* total_ms, double* total_work, int64_t* launches);
+/* Mean elapsed ms of an EMPTY event bracket (`pairs` back-to-back record pairs on `stream`);
+ * subtract it per sampled launch to turn bracket time into kernel time. Host pointer. */
+int fd_prof_calibrate(int pairs, double* ms_per_empty_pair, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Guidance: CLIP image<->text token alignment and tween  (reference guidance.py)

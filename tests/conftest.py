@@ -34,8 +34,26 @@ def golden_scene(seed: int, n_alt: int, dim: int, planted: int, noise: float = 0
     return alt, txt
 
 
+def golden_scene_soft(seed: int, n_alt: int, dim: int, planted: int):
+    '''Same seeded construction as tests/golden/make_guidance_goldens.py::scene_soft
+    (non-adjacent, non-saturating planted matches: clustered guidance yields weights).'''
+    L = 77
+    rng = np.random.default_rng(seed)
+    alt = rng.standard_normal((1, n_alt, dim)).astype(np.float32)
+    txt = rng.standard_normal((1, L, dim)).astype(np.float32)
+    slots = np.arange(2, L - 1, 3)
+    tj = rng.choice(slots, size=min(planted, len(slots)), replace=False)
+    ai = rng.choice(n_alt, size=len(tj), replace=False)
+    for j, i in zip(tj, ai):
+        cos = 0.08 + 0.07 * rng.random()
+        sigma = np.sqrt(1.0 / cos ** 2 - 1.0)
+        txt[0, j] = alt[0, i] + sigma * rng.standard_normal(dim).astype(np.float32)
+    return alt, txt
+
+
 SMALL_SCENES = ['s0_257x64', 's1_257x64', 's2_77x64', 's3_40x64', 's4_257x64_sharp']
 BIG_SCENES = ['b0_257x768', 'b1_257x1024', 'b2_77x768']
+SOFT_SCENES = ['c0_257x768', 'c1_257x1024', 'c2_77x768']
 
 
 def load_scene(g, name):
@@ -44,8 +62,10 @@ def load_scene(g, name):
     import hashlib
     if name + '/alt' in g.files:
         return g[name + '/alt'], g[name + '/txt']
-    seed, n, d, p = (int(v) for v in g[name + '/spec'])
-    alt, txt = golden_scene(seed, n, d, p)
+    spec = [int(v) for v in g[name + '/spec']]
+    seed, n, d, p = spec[:4]
+    alt, txt = golden_scene_soft(seed, n, d, p) if len(spec) > 4 and spec[4] == 1 \
+        else golden_scene(seed, n, d, p)
     sha = hashlib.sha256(alt.tobytes() + txt.tobytes()).digest()
     assert sha == g[name + '/sha'].tobytes(), 'seeded scene regeneration drifted'
     return alt, txt

@@ -36,6 +36,26 @@ def scene(seed: int, n_alt: int, dim: int, planted: int, noise: float = 0.15):
     return alt, txt
 
 
+def scene_soft(seed: int, n_alt: int, dim: int, planted: int):
+    '''Like `scene`, but built so that CLUSTERED guidance has something to do at real embedding
+    widths: planted text tokens sit at NON-ADJACENT positions (every third column at most) and
+    are buried in enough noise (cosine 0.08 .. 0.15 to their guide token) that the 77-way softmax
+    of 100 x cosine does not saturate -- similarities land strictly between 0 and 1, peaks are
+    isolated, and `_clustered_guidance` returns weights instead of raising ZeroDivisionError
+    (guidance.py:112, adjacent equal peaks) as it does on the saturated `scene`s.'''
+    rng = np.random.default_rng(seed)
+    alt = rng.standard_normal((1, n_alt, dim)).astype(np.float32)
+    txt = rng.standard_normal((1, L, dim)).astype(np.float32)
+    slots = np.arange(2, L - 1, 3)
+    tj = rng.choice(slots, size=min(planted, len(slots)), replace=False)
+    ai = rng.choice(n_alt, size=len(tj), replace=False)
+    for j, i in zip(tj, ai):
+        cos = 0.08 + 0.07 * rng.random()
+        sigma = np.sqrt(1.0 / cos ** 2 - 1.0)
+        txt[0, j] = alt[0, i] + sigma * rng.standard_normal(dim).astype(np.float32)
+    return alt, txt
+
+
 TWEEN_SETS = {
     # name: (floor, mult, lin0, lin1, clustered, max_guidance, header_max, mode, reuse)
     'defaults':       (0.5, 0.5, 0.0, 0.5, 0.5, 0.5, 0.15, 1, True),
@@ -74,9 +94,21 @@ def main():
         out[f'{name}/spec'] = np.array([seed, n, d, p], dtype=np.int64)
         out[f'{name}/sha'] = np.frombuffer(
             hashlib.sha256(alt.tobytes() + txt.tobytes()).digest(), dtype=np.uint8)
-    allscenes = {**scenes, **big}
+    # soft scenes (kind 1): non-adjacent, non-saturating matches at the real embedding widths
+    soft = {'c0_257x768': (210, 257, 768, 14), 'c1_257x1024': (211, 257, 1024, 14),
+            'c2_77x768': (212, 77, 768, 10)}
+    for name, (seed, n, d, p) in soft.items():
+        alt, txt = scene_soft(seed, n, d, p)
+        out[f'{name}/spec'] = np.array([seed, n, d, p, 1], dtype=np.int64)
+        out[f'{name}/sha'] = np.frombuffer(
+            hashlib.sha256(alt.tobytes() + txt.tobytes()).digest(), dtype=np.uint8)
+    allscenes = {**scenes, **big, **soft}
+    n_clustered_ok = {}
     for name, (seed, n, d, p) in allscenes.items():
-        alt, txt = scene(seed, n, d, p, noise=0.05 if 'sharp' in name else 0.15)
+        if name in soft:
+            alt, txt = scene_soft(seed, n, d, p)
+        else:
+            alt, txt = scene(seed, n, d, p, noise=0.05 if 'sharp' in name else 0.15)
         ta, tt = torch.from_numpy(alt), torch.from_numpy(txt)
         for mode, reuse in itertools.product((0, 1, 2), (True, False)):
             with quiet:
@@ -112,12 +144,19 @@ def main():
                     w[0] = min(hw, hm) if hw >= 0 else max(hw, -hm)
             key = f'{name}/tween_{tname}'
             out[key + '/weights'] = w.numpy()
+            if cl != 0:
+                n_clustered_ok[name] = n_clustered_ok.get(name, 0) + 1
             if d <= 64:
                 out[key + '/out'] = res.numpy()
             else:
                 out[key + '/out_sha'] = np.frombuffer(
                     hashlib.sha256(res.numpy().tobytes()).digest(), dtype=np.uint8)
                 out[key + '/out_head'] = res.numpy()[0, :, :8].copy()
+    for name in soft:
+        assert n_clustered_ok.get(name, 0) >= 3, (name, n_clustered_ok)
+        m = out[f'{name}/map_m1_r1'][:, 1]
+        assert 0.0 < m[:76].max() < 1.0, (name, m.max())        # not saturated
+    print('clustered tween records with weights per scene:', n_clustered_ok)
     out['tween_sets/names'] = np.array(list(TWEEN_SETS.keys()))
     out['tween_sets/values'] = np.array([[float(v) for v in vals]
                                          for vals in TWEEN_SETS.values()])

@@ -1,12 +1,19 @@
-'''world_size-2 gloo test of the seed-sharding path (the N > 1 data path of bench.py):
-noise drawn once on the host and sliced per rank, per-rank processing, one all-gather;
-the gathered result must equal the single-process result.  CPU only.'''
+'''world_size-2 gloo tests of the seed-sharding path (the N > 1 data path of bench.py,
+SURVEY 8e; the reference's only data-parallel axis is the sequential loop at utils.py:90):
+prompts and CPU-drawn noise sliced contiguously per rank, rank-local guidance + denoising +
+decode, one all-gather of final latents and decoded images.  The gathered result must equal
+the single-process result.  CPU only: the rank-local stage is the mini CPU oracle (the HIP
+path has no CPU fallback), the sharding / gather code is the product's flexdiffuse_amd.dist.'''
 import os
 import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -46,8 +53,75 @@ def test_sharded_equals_unsharded(tmp_path):
     assert torch.equal(gathered, full)
 
 
+PROMPTS = ['a photo of a turtle', 'zeus, god of thunder', 'a deer in a forest', 'neon city at night']
+
+
+def _hot_path_shard(prompts, noise, steps=2):
+    '''Guide.embeds (image-guided, Linear) -> CFG DDIM loop -> decode of one shard, on the mini
+    CPU oracle: what one rank does with its slice (bench.py one_pass).'''
+    from flexdiffuse_amd import build
+    from flexdiffuse_amd.tokenizer import SyntheticTokenizer
+    from oracle import guide_ref, pipeline_ref
+    from test_oracle_clip import synth_image
+    torch.set_num_threads(2)
+    sds = build.synthetic_state_dicts('mini', seed=0)
+    ucfg, vcfg, ccfg = build.configs('mini')
+    tok = SyntheticTokenizer(vocab_size=ccfg.text.vocab_size)
+    g = guide_ref.GuideRef(sds['clip'], ccfg, tok)
+    embeds = g.embeds(prompt=list(prompts), guide=synth_image(20, 512, 512),
+                      guide_threshold_mult=0.0, guide_clustered=0.0, guide_linear=(0.0, 0.5))
+    lat, _ = pipeline_ref.denoise(sds['unet'], ucfg, embeds, g.prompt(''), noise, steps, 8.0)
+    return lat, pipeline_ref.decode_image(sds['vae'], vcfg, lat)
+
+
+def _worker_hot_path(rank, world, port, per_rank, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from flexdiffuse_amd import dist as fdist
+    fdist.init('gloo')
+    noise = fdist.global_noise(world * per_rank, (4, 8, 8), seed=1337)
+    lat, img = _hot_path_shard(fdist.shard(PROMPTS, rank, world, per_rank),
+                               noise[fdist.shard_range(rank, world, per_rank)])
+    all_lat, all_img = fdist.all_gather_samples(lat), fdist.all_gather_samples(img)
+    if rank == 0:
+        torch.save((all_lat, all_img), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_hot_path_equals_single_process(tmp_path):
+    '''Rank-local Guide.embeds on the rank's own prompts + its noise slice + gather of latents
+    and images == one process over the whole batch (results do not depend on the world size).'''
+    from flexdiffuse_amd import dist as fdist
+    world, per_rank = 2, 2
+    out = str(tmp_path / 'hot.pt')
+    mp.spawn(_worker_hot_path, args=(world, _free_port(), per_rank, out), nprocs=world, join=True)
+    all_lat, all_img = torch.load(out)
+    lat, img = _hot_path_shard(PROMPTS, fdist.global_noise(world * per_rank, (4, 8, 8), seed=1337))
+    assert all_lat.shape == lat.shape and all_img.shape == img.shape
+    # per-sample arithmetic is identical; only the GEMM batch differs (2 vs 4 rows per matmul)
+    assert float((all_lat - lat).abs().max()) <= 1e-4 * float(lat.abs().max())
+    assert float((all_img - img).abs().max()) <= 1e-4
+    assert float((lat[0] - lat[2]).abs().max()) > 1e-3      # the prompts / noise differ per sample
+
+
 def test_single_process_is_identity():
     from flexdiffuse_amd import dist as fdist
     x = torch.arange(12.0).view(3, 4)
     assert fdist.all_gather_samples(x) is x
     assert fdist.shard_range(2, 8, 8) == slice(16, 24)
+
+
+def test_bench_refuses_rank_count_it_cannot_start():
+    '''`bench.py --gpus N` must never fall back to one GPU silently: with fewer than N visible
+    devices (none in the CPU container) it exits non-zero, and under a torchrun environment a
+    WORLD_SIZE different from --gpus is an error too.'''
+    bench = os.path.join(ROOT, 'bench.py')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    if torch.cuda.device_count() < 64:
+        r = subprocess.run([sys.executable, bench, '--gpus', '64'], env=env, capture_output=True, timeout=300)
+        assert r.returncode != 0 and b'device(s) visible' in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, bench, '--gpus', '1'], env=dict(env, WORLD_SIZE='2', RANK='0'),
+                       capture_output=True, timeout=300)
+    assert r.returncode != 0 and b'does not match WORLD_SIZE' in r.stderr

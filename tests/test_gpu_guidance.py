@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import BIG_SCENES, SMALL_SCENES, load_scene
+from conftest import BIG_SCENES, SMALL_SCENES, SOFT_SCENES, load_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -21,7 +21,7 @@ def dev():
     return torch.device('cuda:0')
 
 
-@pytest.mark.parametrize('name', SMALL_SCENES + BIG_SCENES)
+@pytest.mark.parametrize('name', SMALL_SCENES + BIG_SCENES + SOFT_SCENES)
 def test_map_emb_vs_reference_goldens(guidance_goldens, dev, name):
     from flexdiffuse_amd import guidance as FG
     g = guidance_goldens
@@ -35,7 +35,7 @@ def test_map_emb_vs_reference_goldens(guidance_goldens, dev, name):
         assert np.max(np.abs(got[:, 1] - want[:, 1])) <= S_TOL, (name, mode, reuse)
 
 
-@pytest.mark.parametrize('name', SMALL_SCENES + BIG_SCENES)
+@pytest.mark.parametrize('name', SMALL_SCENES + BIG_SCENES + SOFT_SCENES)
 def test_tween_vs_reference_goldens(guidance_goldens, dev, name):
     from flexdiffuse_amd import guidance as FG
     from oracle import guidance_ref as G
@@ -112,6 +112,75 @@ def test_underflow_edge_cases(dev):
         got = FG._map_emb(ta, tt, reuse, mode)
         assert np.array_equal(got[:, 0], want[:, 0]), (mode, reuse, got[:8], want[:8])
         assert np.max(np.abs(got[:, 1] - want[:, 1])) <= S_TOL
+
+
+def _realise_profile(s76: np.ndarray, D: int = 128):
+    '''(alt (1,1,D), txt (1,77,D)) whose device similarities reproduce the profile `s76` up to a
+    common scale: with ONE guide token a, S'[0, j] = softmax_j'(100 cos(a, t_j'))[j + 1], so
+    cos(a, t_{j+1}) = 0.5 + ln(p_j) / 100 realises p = s * 0.9 / sum(s) (the header token takes
+    the remaining 0.1).  Peaks, valleys and the `s >= mean(s)` test of _clustered_guidance
+    (guidance.py:135-172) are scale invariant, so the weights must equal the KAT's.  Zero entries
+    become 1e-12 (still far below the mean); equal entries get identical vectors (bit-equal s).'''
+    p = np.maximum(s76.astype(np.float64), 0.0)
+    p = p * (0.9 / p.sum())
+    p = np.maximum(p, 1e-12)
+    prob = np.concatenate([[1.0 - p.sum()], p])                 # text token 0 = header
+    c = 0.5 + np.log(prob) / 100.0
+    alt = np.zeros((1, 1, D), np.float32)
+    alt[0, 0, 0] = 1.0
+    txt = np.zeros((1, 77, D), np.float32)
+    for j in range(77):
+        txt[0, j, 0] = c[j]
+        # equal profile values share the orthogonal axis too: identical vectors, bit-equal s
+        same = [k for k in range(j) if prob[k] == prob[j]]
+        axis = (1 + j % (D - 1)) if not same else int(np.flatnonzero(txt[0, same[0], 1:])[0]) + 1
+        txt[0, j, axis] = np.sqrt(1.0 - c[j] ** 2)
+    return alt, txt
+
+
+def test_clustered_kats_on_device(guidance_goldens, dev):
+    '''The reference-captured `_clustered_guidance` known answers (tests/golden, G3) as DEVICE
+    inputs: embeddings are constructed to realise each KAT's similarity profile, the tween
+    kernel computes the clustered weights from its own similarities, and they must equal (i) the
+    pinned oracle on the device's similarities bit for bit and (ii) the reference's KAT weights
+    whenever the realised profile has the KAT's peak structure.  Adjacent equal peaks must
+    raise ZeroDivisionError like guidance.py:112.'''
+    from flexdiffuse_amd import guidance as FG
+    from oracle import guidance_ref as G
+    g = guidance_goldens
+    matched = zerodiv = 0
+    for k, (s, thr, gain, code, w) in enumerate(zip(g['clustered/s'], g['clustered/thr'], g['clustered/gain'],
+                                                    g['clustered/code'], g['clustered/w'])):
+        s76 = s[:76]
+        # Tweener always thresholds at mean(s): usable KATs are those whose peak set under the
+        # KAT's own threshold equals the peak set under the mean
+        peaks = lambda t: [i for i in range(1, 76) if not (s[i] < t) and s[i - 1] <= s[i] >= s[i + 1]]
+        if peaks(float(thr)) != peaks(float(s.mean())) or not peaks(float(thr)) or gain <= 0:
+            continue
+        alt, txt = _realise_profile(s76)
+        ta, tt = torch.from_numpy(alt).to(dev), torch.from_numpy(txt).to(dev)
+        tw = FG.Tweener((0.5, 0.0), (0.0, 0.0), float(gain), 10.0, 1.0, 1, True)
+        if code == 2:
+            with pytest.raises(ZeroDivisionError):
+                tw.tween(tt, ta)
+            zerodiv += 1
+            continue
+        tw.tween(tt, ta)
+        idx, sd = tw.last_map
+        sdev = sd[0].cpu().numpy().astype(np.float64)
+        scale = 0.9 / max(float(np.maximum(s76, 0).sum()), 1e-30)
+        assert np.max(np.abs(sdev[:76] - np.maximum(s76 * scale, 1e-12))) <= 1e-4 * (s76.max() * scale), k
+        mapped = np.zeros((77, 2))
+        mapped[:, 1] = sdev
+        want = G.tween_weights(mapped, (0.5, 0.0), (0.0, 0.0), float(gain), 1.0)
+        got = tw.last_weights[0].cpu().numpy()
+        assert np.array_equal(got, want.numpy()), f'KAT {k}: device weights != oracle on device s'
+        dpeaks = [i for i in range(1, 76) if not (sdev[i] < sdev.mean()) and sdev[i - 1] <= sdev[i] >= sdev[i + 1]]
+        if dpeaks == peaks(float(thr)):
+            # blend(zeros, cw) with cw >= 0 is cw itself (guidance.py:186-189)
+            assert np.array_equal(got, w), f'KAT {k}: device weights != reference KAT weights'
+            matched += 1
+    assert matched >= 8 and zerodiv >= 1, (matched, zerodiv)
 
 
 @pytest.mark.parametrize('k', [0, 1, 2])

@@ -89,9 +89,66 @@ def test_guide_embeds_vs_reference_goldens(dev):
         want = cg['guide/' + name]
         assert got.shape == want.shape, name
         assert np.max(np.abs(got - want)) < 3e-2 * max(1.0, np.abs(want).max()), name
-    out = g.embeds(prompt=p[0], guide=img, guide_threshold_mult=0.0, guide_clustered=0.0,
-                   guide_linear=(0.0, 0.5), guide_max_guidance=0.5)
-    assert out.shape == cg['guide/image_linear'].shape
+    # ---- the tween branches (guidance.py:409-449), value-checked: the DEVICE text / image
+    # embeddings go through the CPU oracle's tween, which must reproduce g.embeds(...) --
+    # bit-exact when the oracle is fed the device's own mapping (similarities differ in the
+    # last fp32 bits between the MFMA and the numpy mat-vec), and with equal guide indices and
+    # |delta| <= 1e-5 when the oracle maps by itself.  Against the reference's goldens (fp32
+    # towers) the loose tower bound holds.
+    import numpy as _np
+    from oracle import guidance_ref as G
+    C3 = dict(guide_threshold_floor=0.75, guide_threshold_mult=0.25, guide_clustered=0.25,
+              guide_linear=(0.0, 0.0), guide_max_guidance=0.35, guide_header_max=0.0)
+    cases = {
+        'image_linear': (p[0], dict(guide_threshold_mult=0.0, guide_clustered=0.0,
+                                    guide_linear=(0.0, 0.5), guide_max_guidance=0.5)),
+        'image_thr': (p[1], dict(guide_threshold_mult=0.25, guide_threshold_floor=0.05,
+                                 guide_clustered=0.0, guide_linear=(0.0, 0.0),
+                                 guide_max_guidance=0.35, guide_header_max=0.0)),
+        'c3_clustered_threshold': (p[0], C3),
+        'concepts': (p[0], dict(mapping_concepts='turtle photo', guide_clustered=0.0)),
+    }
+    img_dev = g.encoder.image(img).float()
+    for name, (prompt, kw) in cases.items():
+        text_dev = g.encoder.prompt(prompt).float()
+        try:
+            out = g.embeds(prompt=prompt, guide=img, **kw).cpu()
+        except ZeroDivisionError:
+            with pytest.raises(ZeroDivisionError):      # the oracle must raise on the same input
+                G.tween(text_dev.cpu(), img_dev.cpu(), (kw.get('guide_threshold_floor', 0.5),
+                        kw.get('guide_threshold_mult', 0.5)), kw.get('guide_linear', (0.0, 0.5)),
+                        kw.get('guide_clustered', 0.5), kw.get('guide_max_guidance', 0.5),
+                        kw.get('guide_header_max', 0.15), 1, True)
+            continue
+        tw = g.last_tweener
+        idx, sdev = tw.last_map
+        mapped = _np.zeros((77, 2))
+        mapped[:, 0] = idx[0].cpu().numpy()
+        mapped[:, 1] = sdev[0].cpu().numpy().astype(_np.float64)
+        args = ((kw.get('guide_threshold_floor', 0.5), kw.get('guide_threshold_mult', 0.5)),
+                kw.get('guide_linear', (0.0, 0.5)), kw.get('guide_clustered', 0.5),
+                kw.get('guide_max_guidance', 0.5), kw.get('guide_header_max', 0.15), 1, True)
+        want, w, _ = G.tween(text_dev.cpu(), img_dev.cpu(), *args, mapped=mapped)
+        own, _, own_map = G.tween(text_dev.cpu(), img_dev.cpu(), *args)
+        if kw.get('mapping_concepts'):
+            concept_dev = g.encoder.prompt(kw['mapping_concepts']).float().cpu()
+            want = G.concept_override(img_dev.cpu(), concept_dev, text_dev.cpu(), out=want)
+            own = G.concept_override(img_dev.cpu(), concept_dev, text_dev.cpu(), out=own)
+        assert _np.array_equal(w.numpy(), tw.last_weights[0].cpu().numpy()), name
+        assert torch.equal(out, want), f'{name}: Guide.embeds != oracle tween of the device embeddings'
+        assert _np.array_equal(own_map[:, 0], mapped[:, 0]), name
+        assert float((out - own).abs().max()) <= 1e-5, name
+        assert float((out - text_dev.cpu()).abs().max()) > 1e-3, f'{name}: the guide changed nothing'
+        if 'guide/' + name in cg.files:
+            ref = cg['guide/' + name]
+            assert out.shape == ref.shape
+            assert _np.max(_np.abs(out.numpy() - ref)) < 3e-2 * max(1.0, _np.abs(ref).max()), name
+    # a batch of prompts with a guide (the reference raises IndexError there, E2): row b equals
+    # the single-prompt result
+    both = g.embeds(prompt=p[:2], guide=img, **cases['image_linear'][1]).cpu()
+    for b in range(2):
+        one = g.embeds(prompt=p[b], guide=img, **cases['image_linear'][1]).cpu()
+        assert torch.equal(both[b], one[0])
     with pytest.raises(ValueError):
         g.embeds(prompt=3)
     with pytest.raises(ValueError):
@@ -271,6 +328,48 @@ def test_sd15_c1_pipeline_psnr(sd15, dev):
     print(f'SD1.5 c1: latent rel err {relerr(pipe.last_latents, lat_ref):.4f}, PSNR {p:.1f} dB, '
           f'image std {float(img_ref.std()):.3f}')
     assert out.images.shape == (1, hw, hw, 3)
+    assert float(img_ref.std()) > 0.02, 'degenerate image: parity would be vacuous'
+    assert p >= 40.0, p
+
+
+def test_sd15_c2_headline_psnr(sd15, dev):
+    '''BASELINE configs[1] -- the headline configuration -- at batch 1: SD1.5, 512x512, 50 DDIM
+    steps, CFG 8, Linear image guidance.  Device path (Guide.embeds with the ViT-L/14 guide ->
+    FlexPipeline, fp16) vs the CPU fp32 oracle of the same sample, whose 100 UNet forwards are
+    cached as data in tests/golden/c2_oracle.npz (tests/golden/make_c2_oracle.py; the oracle's
+    VAE decode runs here).  Integer timestep lists equal, guided embeddings close, final-image
+    PSNR >= 40 dB (north_star), latent error reported.  Reference loop: pipeline/flex.py:262-287.'''
+    import hashlib
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_c2_oracle import C2, c2_inputs
+    from flexdiffuse_amd import Guide, SimpleGuide
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from oracle import pipeline_ref
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = sd15
+    o = np.load(os.path.join(GOLDEN, 'c2_oracle.npz'))
+    steps, size = int(o['steps'][0]), int(o['size'][0])
+    assert (steps, size) == (50, 512)
+    prompt, img, lat0 = c2_inputs(size)
+    assert hashlib.sha256(lat0.numpy().tobytes()).digest() == o['lat0_sha'].tobytes()
+    g = Guide(clip, tok, device='cuda')
+    embeds = g.embeds(prompt=prompt, guide=img, **C2['embeds_kw'])
+    emb_err = float((embeds.float().cpu() - torch.from_numpy(o['embeds'])).abs().max())
+    text_moved = float((torch.from_numpy(o['embeds']) - torch.from_numpy(o['text'])).abs().max())
+    assert text_moved > 0.1, 'the oracle guidance changed nothing: parity would be vacuous'
+    assert emb_err < 3e-2 * max(1.0, float(np.abs(o['embeds']).max())), emb_err
+    enc = CLIPEncoder(clip, tok)
+    out = pipe(guide=SimpleGuide(enc, pipe.unet, C2['guidance'], steps, embeds), init_size=(size, size),
+               latents=lat0, output_type='np')
+    assert [int(t) for t in o['timesteps']] == [int(t) for t in pipe.scheduler.timesteps] \
+        == list(range(980, -1, -20))
+    lat_ref = torch.from_numpy(o['latents'])
+    img_ref = pipeline_ref.decode_image(sds['vae'], vcfg, lat_ref)
+    p = pipeline_ref.psnr(pipe.last_images.cpu(), img_ref)
+    print(f'SD1.5 c2 (512x512, 50 steps, Linear image guidance): guided-embedding max err {emb_err:.4f}, '
+          f'latent rel err {relerr(pipe.last_latents, lat_ref):.4f}, PSNR {p:.1f} dB, '
+          f'image std {float(img_ref.std()):.3f}')
+    assert out.images.shape == (1, size, size, 3)
     assert float(img_ref.std()) > 0.02, 'degenerate image: parity would be vacuous'
     assert p >= 40.0, p
 

@@ -7,11 +7,11 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import BIG_SCENES, SMALL_SCENES, load_scene
+from conftest import BIG_SCENES, SMALL_SCENES, SOFT_SCENES, load_scene
 from oracle import guidance_ref as G
 
 
-@pytest.mark.parametrize('name', SMALL_SCENES + BIG_SCENES)
+@pytest.mark.parametrize('name', SMALL_SCENES + BIG_SCENES + SOFT_SCENES)
 def test_map_emb_matches_reference(guidance_goldens, name):
     g = guidance_goldens
     alt, txt = load_scene(g, name)
@@ -24,7 +24,7 @@ def test_map_emb_matches_reference(guidance_goldens, name):
         assert np.max(np.abs(got[:, 1] - want[:, 1])) <= 1e-5
 
 
-@pytest.mark.parametrize('name', SMALL_SCENES + BIG_SCENES)
+@pytest.mark.parametrize('name', SMALL_SCENES + BIG_SCENES + SOFT_SCENES)
 def test_tween_matches_reference(guidance_goldens, name):
     g = guidance_goldens
     alt, txt = load_scene(g, name)
@@ -46,6 +46,23 @@ def test_tween_matches_reference(guidance_goldens, name):
             assert np.max(np.abs(out.numpy()[0, :, :8] - g[key + '/out_head'])) <= 1e-6
             sha = hashlib.sha256(out.numpy().tobytes()).digest()
             assert sha == g[key + '/out_sha'].tobytes(), key + ' (not bit-exact)'
+
+
+def test_soft_scenes_exercise_clustered_guidance_at_real_widths(guidance_goldens):
+    '''The D = 768 / 1024 scenes with non-adjacent, non-saturating matches must yield clustered
+    WEIGHTS (not the ZeroDivisionError record the saturated scenes give) for every clustered
+    parameter set, so the clustered / threshold path is value-pinned at the real widths.'''
+    g = guidance_goldens
+    names = [str(n) for n in g['tween_sets/names']]
+    clustered_sets = [n for n, v in zip(names, g['tween_sets/values']) if v[4] != 0]
+    assert len(clustered_sets) >= 6
+    for scene in SOFT_SCENES:
+        have = [n for n in clustered_sets if f'{scene}/tween_{n}/weights' in g.files]
+        assert len(have) >= 3, (scene, have)
+        s = g[f'{scene}/map_m1_r1'][:76, 1]
+        assert 0.0 < s.max() < 1.0 and len(np.unique(np.round(s, 4))) > 60     # not saturated
+        w = g[f'{scene}/tween_c3_clust_thr/weights']
+        assert 0 < (w > 0).sum() < 77 and len(np.unique(w)) >= 4               # peaks, ramps and valleys
 
 
 def test_clustered_and_blend_kats(guidance_goldens):
