@@ -59,8 +59,15 @@ class CompositeGuide(GuideBase):
         bg = stack[first]
         for k, e in enumerate(self.entities):
             (ow, oh), (sw, sh) = e.offset_blocks, e.size_blocks
+            # composition/guide.py:86-98 slices noise[:, :, oh:oh+sh, ow:ow+sw]: Python slice
+            # semantics -- a box past the canvas is clipped, a NEGATIVE start counts from the end
+            # of the axis (usually leaving an empty box, i.e. no blend at all)
+            y0, y1, _ = slice(oh, oh + sh).indices(H)
+            x0, x1, _ = slice(ow, ow + sw).indices(W)
+            if y1 <= y0 or x1 <= x0:
+                continue
             hip.call('fd_region_blend_f32', bg.data_ptr(), stack[first + 1 + k].data_ptr(), C, H, W,
-                     oh, ow, sh, sw, float(e.blend), hip.stream())
+                     y0, x0, y1 - y0, x1 - x0, float(e.blend), hip.stream())
         if not self.classifier_free_guidance:
             return bg[None].contiguous()
         out = torch.empty((1, C, H, W), dtype=torch.float32, device=latents.device)

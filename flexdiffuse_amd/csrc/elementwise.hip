@@ -316,9 +316,10 @@ __global__ void k_region_blend(float* __restrict__ dst, const float* __restrict_
 extern "C" int fd_region_blend_f32(float* dst, const float* src, int C, int H, int W, int oy, int ox,
                                    int sh, int sw, float blend, void* stream) {
     FD_CHECK_ARG(dst && src && C > 0 && H > 0 && W > 0, FD_EINVAL, "fd_region_blend_f32: args");
-    if (oy < 0) { sh += oy; oy = 0; }
-    if (ox < 0) { sw += ox; ox = 0; }
-    if (oy + sh > H) sh = H - oy;        // python slicing clamps the box to the tensor
+    // the host resolves Python's slice semantics (a negative start counts from the end of the
+    // axis: composition/guide.py:86-98) before calling; here only the clip at the far edge remains
+    FD_CHECK_ARG(oy >= 0 && ox >= 0, FD_EINVAL, "fd_region_blend_f32: negative box origin (%d, %d)", oy, ox);
+    if (oy + sh > H) sh = H - oy;
     if (ox + sw > W) sw = W - ox;
     if (sh <= 0 || sw <= 0) return FD_OK;
     const int total = C * sh * sw;

@@ -1256,6 +1256,23 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     }
     if (d->tile) best_tile = d->tile;
     if (d->split_k > 0) best_split = d->split_k;
+    {
+        // The many-wave tiles exist only on the LDS-DMA path, whose buffer descriptors address a
+        // tensor through 32-bit byte offsets (< 2 GiB).  Larger operands go to the register-staged
+        // 4-wave kernel (32-bit ELEMENT offsets: < 2^31 halfs = 4 GiB); beyond that, refuse.
+        const unsigned long long a_elems =
+            g.mode == MODE_CONV ? (unsigned long long)(g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi * g.Cin
+                                : (unsigned long long)(g.M - 1) * g.lda + g.K;
+        const unsigned long long w_elems = (unsigned long long)(g.N - 1) * g.ldw + g.K;
+        const unsigned long long c_elems = (unsigned long long)(g.M - 1) * g.ldc + g.N;
+        FD_CHECK_ARG(a_elems < 0x7fffffffull && w_elems < 0x7fffffffull && c_elems < 0x7fffffffull, FD_ESHAPE,
+                     "fd_gemm_f16: operand of %llu elements exceeds the 2^31-element addressing limit; "
+                     "split the batch", a_elems > w_elems ? a_elems : w_elems);
+        if (2 * a_elems >= 0x7fffffffull || 2 * w_elems >= 0x7fffffffull) {
+            best_tile = geglu ? 1 : (g.N % 160 == 0 ? 2 : 1);   // 128x160 / 128x128, 4 waves
+            if (g.N <= 64) best_tile = 3;
+        }
+    }
     if (best_split > 1)
         FD_CHECK_ARG(!geglu && batch == 1 && g.N % 4 == 0 && g.ws &&
                          (size_t)best_split * g.M * g.N * 4 <= (size_t)d->workspace_bytes,

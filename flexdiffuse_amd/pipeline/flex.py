@@ -120,7 +120,10 @@ class FlexPipeline():
         if not self.use_graph or hip.prof_is_on():   # event timing needs eager launches
             return self.unet.forward_nhwc(latents, t, ctx, rep=rep)
         self.unet.set_context(ctx)               # eager, in place: the graph reads these buffers
-        key = (latents.data_ptr(), tuple(latents.shape), rep, tuple(ctx.shape))
+        # ctx_generation changes when the UNet had to reallocate its cached K / V^T (a call with
+        # another context shape in between): a graph captured before that reads freed memory
+        key = (latents.data_ptr(), tuple(latents.shape), rep, tuple(ctx.shape),
+               getattr(self.unet, 'ctx_generation', 0))
         entry = self._graphs.get(key)
         if entry is None:
             t_static = torch.zeros((1,), dtype=torch.float32, device=latents.device)

@@ -140,6 +140,10 @@ class UNet2DConditionModel():
         self._attn_layers = [a for blk in self.down for a in blk['attn'] if a] + [self.mid_attn] + \
                             [a for blk in self.up for a in blk['attn'] if a]
         self._ctx_key = None
+        # bumped whenever set_context REALLOCATES the cached K / V^T buffers (instead of rewriting
+        # them in place): a captured HIP graph of the forward holds the old addresses and must not
+        # be replayed after that (FlexPipeline keys its graph cache on this counter)
+        self.ctx_generation = 0
         self._cat_plan = self._plan_concats()
 
     def _plan_concats(self) -> List[Optional[int]]:
@@ -190,6 +194,7 @@ class UNet2DConditionModel():
         c16 = ops.cast_f16(ctx.reshape(Be * L, D)) if ctx.dtype != torch.float16 \
             else ctx.reshape(Be * L, D).contiguous()
         ldv = (L + 7) // 8 * 8
+        realloc = False
         for a in self._attn_layers:
             old = a.ctx_kv
             if old is not None and old[0].shape == (Be * L, a.C) and old[1].shape == (Be, a.C, ldv):
@@ -199,6 +204,9 @@ class UNet2DConditionModel():
                 ops.gemm_vt(c16, a.v2, Be, L, ldv, out=old[1])
             else:
                 a.ctx_kv = (ops.gemm(c16, a.k2), ops.gemm_vt(c16, a.v2, Be, L, ldv), L)
+                realloc = True
+        if realloc:
+            self.ctx_generation += 1
         self._ctx_key = key
         self._ctx_ref = ctx  # keep the tensor alive so its data_ptr cannot be recycled
 

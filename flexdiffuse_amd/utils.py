@@ -2,6 +2,9 @@
 (utils.py:54-166: seed handling :78-83, sequential sample batches :90, argument plumbing of
 `gen` :114-166) and `image_grid` (:36-50).
 
+`Runner.compose` (utils.py:168-207) is the caller of CompositeGuide: entity rows are parsed with
+the reference's forgiving try/except, empty prompts dropped, a `Schema` built and run.
+
 Out of scope here: model download (`from_pretrained`), PNG / grid files
 and the filename scheme -- `Runner` takes state dicts (or builds seeded synthetic ones) and
 returns the images.  Differences from the reference, all deliberate:
@@ -19,6 +22,7 @@ import torch
 from . import build
 from .encode.clip import CLIPEncoder
 from .guidance import Guide
+from .composition import CompositeGuide, EntitySchema, Schema
 from .pipeline.guide import GuideBase, SimpleGuide
 
 MAX_SEED = 2147483647
@@ -99,3 +103,40 @@ class Runner():
         pipeline_guide = SimpleGuide(self.encoder, self.pipe.unet, guidance_scale, steps,
                                      guide_embeds)
         return self._run(samples, pipeline_guide, init_image, init_size, strength, debug)
+
+    def compose(self,
+                bg_prompt: str = '',
+                entities_df: Sequence[Sequence[Any]] = (),
+                start_style: str = '',
+                end_style: str = '',
+                style_blend: Tuple[float, float] = (0.0, 1.0),
+                init_image=None,
+                batches: int = 4,
+                strength: float = 0.7,
+                steps: int = 30,
+                guidance_scale: float = 8.0,
+                init_size: Tuple[int, int] = (512, 512),
+                seed: Optional[int] = None,
+                debug: bool = False):
+        '''Same arguments and defaults as utils.py:168-181; returns (images, grid).  Each row of
+        `entities_df` is [prompt, offset_x, offset_y, width, height, blend] (a DataFrame is
+        accepted through its `_values`, utils.py:198-199); a row that does not parse is reported
+        and skipped, rows with an empty prompt are dropped (utils.py:188-201).'''
+        self._set_seed(seed)
+
+        def _row_to_ent(row) -> Optional[EntitySchema]:
+            try:
+                return EntitySchema(str(row[0]).strip(), (int(row[1]), int(row[2])),
+                                    (int(row[3]), int(row[4])), float(row[5]))
+            except Exception as ex:
+                print('Failed to build EntitySchema:', ex)
+                return None
+
+        if hasattr(entities_df, '_values'):
+            entities_df = entities_df._values
+        rows = [_row_to_ent(r) for r in entities_df]
+        rows = [r for r in rows if r and r.prompt]
+        schema = Schema(bg_prompt, start_style, end_style, style_blend, rows)
+        self.last_schema = schema
+        pipeline_guide = CompositeGuide(self.encoder, self.pipe.unet, guidance_scale, schema, steps)
+        return self._run(batches, pipeline_guide, init_image, init_size, strength, debug)

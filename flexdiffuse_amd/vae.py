@@ -136,8 +136,19 @@ class AutoencoderKL():
 
     # ---- decode ---------------------------------------------------------------------------
     def decode_nhwc(self, z: torch.Tensor, scale: float = 1.0) -> Act:
-        '''(B,4,h,w) fp32 latents (multiplied by `scale`) -> NHWC fp32 image Act [B*H*W][4].'''
+        '''(B,4,h,w) fp32 latents (multiplied by `scale`) -> NHWC fp32 image Act [B*H*W][4].
+        Large batches are decoded in sample chunks: the LDS-DMA GEMM tiles and GroupNorm address
+        a tensor through 32-bit buffer offsets, so every activation must stay below 2 GiB -- the
+        widest is the full-resolution map of the narrowest decoder level (128 channels for SD:
+        32 images at 512x512, 14 at 768x768); the chunks keep it at <= 1 GiB.'''
         hip.require_device(z)
+        B, _, hh, ww = z.shape
+        up = 2 ** (len(self.cfg.block_out_channels) - 1)
+        per_sample = hh * up * ww * up * self.cfg.block_out_channels[0]      # elements (fp16)
+        chunk = max(1, getattr(self, 'decode_chunk_elems', 1 << 29) // max(per_sample, 1))
+        if B > chunk:
+            parts = [self.decode_nhwc(z[i:i + chunk], scale) for i in range(0, B, chunk)]
+            return Act(torch.cat([p.t for p in parts]), B, parts[0].H, parts[0].W)
         x = ops.nchw_to_nhwc(z, c_pad=8, scale=scale)
         h = Act(ops.gemm(x.t, self.post_quant), x.B, x.H, x.W)
         h = ops.conv2d(h, self.d_conv_in)

@@ -233,7 +233,9 @@ int fd_vit_assemble_f16(const void* patches, const void* cls, const void* pos, v
 /* diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0): t [B] fp32 -> fp16 [B][dim]. */
 int fd_timestep_embedding_f16(const float* t, void* out, int B, int dim, void* stream);
 /* CompositeGuide region blend (reference composition/guide.py:86-98), NCHW fp32 [C][H][W]:
- * dst[:, oy:oy+sh, ox:ox+sw] += blend * (src - dst) on the same box (clamped like slicing). */
+ * dst[:, oy:oy+sh, ox:ox+sw] += blend * (src - dst) on the same box.  oy, ox >= 0: the host
+ * resolves Python's slice semantics (negative starts count from the end of the axis) first;
+ * the box is clipped to the canvas. */
 int fd_region_blend_f32(float* dst, const float* src, int C, int H, int W, int oy, int ox, int sh,
                         int sw, float blend, void* stream);
 int fd_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);

@@ -14,15 +14,20 @@ VAE_SCALE = 0.18215
 
 
 @torch.no_grad()
-def noise_pred(sd_unet, ucfg, latents, t, embeds, uncond, guidance):
-    '''pipeline/guide.py:46-64.'''
+def noise_pred(sd_unet, ucfg, latents, t, embeds, uncond, guidance, unet_fn=None):
+    '''pipeline/guide.py:46-64.  PINNED (this function, not the UNet it calls) by
+    tests/golden/backhalf_goldens.npz `simple/*`: the reference's own SimpleGuide.noise_pred run
+    with a recording stub UNet (tests/golden/make_backhalf_goldens.py); `unet_fn(latents, t, ctx)`
+    replays that stub in tests/test_oracle_backhalf.py.'''
+    if unet_fn is None:
+        unet_fn = lambda x, tt, ctx: unet_ref.unet_forward(sd_unet, ucfg, x, tt, ctx)
     B = latents.shape[0]
     if guidance > 1.0:
         ctx = torch.cat([uncond.expand(B, -1, -1), embeds])
-        out = unet_ref.unet_forward(sd_unet, ucfg, torch.cat([latents] * 2), t, ctx)
+        out = unet_fn(torch.cat([latents] * 2), t, ctx)
         u, c = out.chunk(2)
         return u + guidance * (c - u)
-    return unet_ref.unet_forward(sd_unet, ucfg, latents, t, embeds)
+    return unet_fn(latents, t, embeds)
 
 
 @torch.no_grad()

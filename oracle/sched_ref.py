@@ -77,7 +77,10 @@ def lms_loop(eps_fn, latents, steps, n_train=1000, order=4):
 
 
 def composite_noise_pred(unet_fn, latents, uncond, bg, entities, guidance):
-    '''composition/guide.py:55-99 for batch_size 1.  entities: [(embed, (ow,oh), (sw,sh), blend)].'''
+    '''composition/guide.py:55-99 for batch_size 1.  entities: [(embed, (ow,oh), (sw,sh), blend)].
+    PINNED by tests/golden/backhalf_goldens.npz `composite/*` (the reference's own
+    CompositeGuide.noise_pred with a recording stub UNet, incl. clipped and negative-offset
+    boxes: torch slicing has Python's semantics, a negative start counts from the end).'''
     rows = [bg] + [e[0] for e in entities]
     cfg = guidance > 1.0
     if cfg:

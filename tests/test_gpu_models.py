@@ -634,3 +634,199 @@ def test_sd15_c4_size_img2img_properties(dev):
     assert np.isfinite(outs[0]).all() and outs[0].min() >= 0.0 and outs[0].max() <= 1.0
     assert np.array_equal(outs[0], outs[1])           # deterministic kernels, same generator
     assert float(np.abs(outs[0][0] - outs[0][1]).mean()) > 1e-3   # the two prompts differ
+
+
+# ---- the reference's own back-half code, replayed on the device -------------------------------
+class _ReplayUNet():
+    '''Stub with the surface the product guides use (`forward_nhwc`): checks it is called with the
+    latents / embedding stack the REFERENCE passed to its UNet (tests/golden/backhalf_goldens.npz)
+    and returns the recorded UNet output as NHWC fp32.'''
+
+    def __init__(self, g, key, dev):
+        self.lat = torch.from_numpy(g[key + '/unet_latents'])
+        self.ctx = torch.from_numpy(g[key + '/unet_ctx'])
+        out = torch.from_numpy(g[key + '/unet_out'])
+        self.out = out.permute(0, 2, 3, 1).reshape(-1, out.shape[1]).contiguous().to(dev)
+        self.calls = 0
+
+    def forward_nhwc(self, latents, step, ctx, rep=1):
+        assert torch.equal(torch.cat([latents.cpu()] * rep), self.lat)
+        assert torch.equal(ctx.float().cpu(), self.ctx), 'embedding stack ordered differently'
+        self.calls += 1
+        return self.out
+
+
+class _StubEncoder():
+    def __init__(self, dev):
+        self.dev = dev
+
+    def prompt(self, p):
+        from test_oracle_backhalf import stub_embed
+        ps = [p] if isinstance(p, str) else list(p)
+        return torch.cat([stub_embed(s) for s in ps]).to(self.dev)
+
+
+@pytest.mark.parametrize('name', ['cfg_b2', 'nocfg_b2', 'cfg_b1'])
+def test_simple_guide_noise_pred_vs_reference_goldens(dev, name):
+    '''Device SimpleGuide / PromptGuide.noise_pred (stack order + CFG combine kernel) against the
+    reference's own pipeline/guide.py:46-64 run with a recording stub UNet.'''
+    from flexdiffuse_amd import PromptGuide
+    g = np.load(os.path.join(GOLDEN, 'backhalf_goldens.npz'))
+    key = f'simple/{name}'
+    unet = _ReplayUNet(g, key, dev)
+    guide = PromptGuide(_StubEncoder(dev), unet, float(g[key + '/guidance'][0]), 10,
+                        [str(p) for p in g[key + '/prompts']])
+    assert guide.batch_size == len(g[key + '/prompts'])
+    got = guide.noise_pred(torch.from_numpy(g[key + '/latents']).to(dev), int(g[key + '/step'][0]))
+    want = torch.from_numpy(g[key + '/noise_pred'])
+    assert unet.calls == 1 and got.shape == want.shape
+    # u + g (t - u): the kernel may contract to an fma -> last-bit differences only
+    assert float((got.cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max()), name
+
+
+def test_composite_guide_vs_reference_goldens(dev):
+    '''Device CompositeGuide.noise_pred (region blend kernel with Python slice semantics --
+    clipped and negative-offset boxes --, CFG) against the reference's own
+    composition/guide.py:56-139 run with a recording stub UNet.'''
+    from flexdiffuse_amd.composition import CompositeGuide, EntitySchema, Schema
+    g = np.load(os.path.join(GOLDEN, 'backhalf_goldens.npz'))
+    for name in (str(n) for n in g['composite/names']):
+        key = f'composite/{name}'
+        ents = [EntitySchema(str(p), (int(e[0]), int(e[1])), (int(e[2]), int(e[3])), float(b))
+                for e, b, p in zip(g[key + '/entities'], g[key + '/blend'], g[key + '/entity_prompts'])]
+        schema = Schema(str(g['composite/background_prompt']), 'oil painting', 'photograph', (0.0, 1.0), ents)
+        unet = _ReplayUNet(g, key, dev)
+        guide = CompositeGuide(_StubEncoder(dev), unet, float(g[key + '/guidance'][0]), schema, 10)
+        got = guide.noise_pred(torch.from_numpy(g[key + '/latents']).to(dev), 500)
+        want = torch.from_numpy(g[key + '/noise_pred'])
+        assert unet.calls == 1 and got.shape == want.shape, name
+        assert float((got.cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max()), name
+
+
+def test_runner_compose(dev):
+    '''utils.Runner.compose (reference utils.py:168-207): row parsing -> Schema -> CompositeGuide
+    -> sequential batches through the generic guide protocol; reproducible from the seed and equal
+    to driving CompositeGuide by hand.'''
+    from flexdiffuse_amd import Runner
+    from flexdiffuse_amd.composition import CompositeGuide
+    r = Runner(preset='mini', device='cuda')
+    rows = [['a deer', 0, 16, 64, 48, 0.8], ['', 0, 0, 8, 8, 0.5], ['bad', 'x', 0, 8, 8, 0.5],
+            ['a red bird', 64, 0, 64, 64, 0.5]]
+    imgs, grid = r.compose('a forest at dawn', rows, init_size=(128, 128), steps=3, batches=2, seed=9)
+    assert len(imgs) == 2 and [e.prompt for e in r.last_schema.entities] == ['a deer', 'a red bird']
+    again, _ = r.compose('a forest at dawn', rows, init_size=(128, 128), steps=3, batches=2, seed=9)
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(imgs, again))
+    assert not np.array_equal(np.asarray(imgs[0]), np.asarray(imgs[1]))   # the generator advances
+    guide = CompositeGuide(r.encoder, r.pipe.unet, 8.0, r.last_schema, 3)
+    out = r.pipe(guide=guide, init_size=(128, 128), generator=torch.Generator('cpu').manual_seed(9))
+    assert np.array_equal(np.asarray(out['sample'][0]), np.asarray(imgs[0]))
+
+
+# ---- full-size towers / decoder and the c5 (OpenCLIP ViT-H) shapes ------------------------------
+def test_vit_h_shaped_mini_towers_vs_oracle(dev):
+    '''BASELINE configs[4]'s guide towers in miniature: OpenCLIP-style erf-GELU MLPs, vision
+    head dim 80 (the non-prescaled k_attention_w8<96,5> path), text head dim 64, 2 layers each,
+    against oracle.clip_ref on fp16-exact seeded weights.  Reference call sites:
+    encode/clip.py:47-65 (prompt), :86-100 (image).'''
+    from flexdiffuse_amd import weights as W
+    from flexdiffuse_amd.clip import CLIPModel
+    from flexdiffuse_amd.encode.clip import CLIPEncoder, clip_pixels, preprocess
+    from flexdiffuse_amd.tokenizer import SyntheticTokenizer
+    from oracle import clip_ref
+    from test_oracle_clip import synth_image
+    cfg = W.CLIPConfig(
+        text=W.CLIPTextConfig(vocab_size=512, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                              num_attention_heads=2, hidden_act='gelu'),
+        vision=W.CLIPVisionConfig(hidden_size=160, intermediate_size=320, num_hidden_layers=2,
+                                  num_attention_heads=2, hidden_act='gelu'),
+        projection_dim=128)
+    sd = W.synth_state_dict(W.clip_param_shapes(cfg), seed=7, branch_gain=1.0)
+    sd = {k: v.half().float() for k, v in sd.items()}
+    clip = CLIPModel(sd, cfg, dev)
+    tok = SyntheticTokenizer(vocab_size=512)
+    enc = CLIPEncoder(clip, tok)
+    img = synth_image(21, 900, 600)
+    want = clip_ref.image_tokens(sd, cfg, clip_ref.clip_pixels(clip_ref.preprocess(img)))
+    got = enc.image(img)
+    assert got.shape == want.shape == (1, 257, 128)
+    assert relerr(got, want) < 2e-2, relerr(got, want)
+    for p in ('a photo of a turtle', ['zeus, oil painting', '']):
+        want = clip_ref.text_hidden(sd, cfg, tok(p).input_ids)
+        assert relerr(enc.prompt(p), want) < 2e-2
+
+
+def test_sd15_full_size_vit_l14_and_vae_decode_vs_oracle(sd15, dev):
+    '''The two full-size stages the bench runs but nothing else compares: the ViT-L/14 guide tower
+    (257 x 1024, 24 layers; encode/clip.py:86-100) and the VAE decoder at 64x64 latents -> 512x512
+    (pipeline/flex.py:112-124), each against the CPU fp32 oracle, 3 % of the output magnitude.'''
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from oracle import clip_ref, vae_ref
+    from test_oracle_clip import synth_image
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = sd15
+    enc = CLIPEncoder(clip, tok)
+    img = synth_image(2, 512, 512)
+    want = clip_ref.image_tokens(sds['clip'], ccfg, clip_ref.clip_pixels(clip_ref.preprocess(img)))
+    got = enc.image(img)
+    e = relerr(got, want)
+    print(f'full-size ViT-L/14 guide tokens vs CPU oracle: rel err {e:.4f}')
+    assert got.shape == (1, 257, 768) and e < 3e-2
+    z = torch.randn((1, 4, 64, 64), generator=torch.Generator().manual_seed(3))
+    want = vae_ref.vae_decode(sds['vae'], vcfg, z)
+    got = pipe.vae.decode(z.to(dev)).sample
+    e = relerr(got, want)
+    print(f'full-size VAE decode 64x64 -> 512x512 vs CPU oracle: rel err {e:.4f}')
+    assert got.shape == (1, 3, 512, 512) and e < 3e-2
+
+
+def test_sd21_c5_vit_h_guide_vs_oracle(dev):
+    '''BASELINE configs[4] guide stage at full size: OpenCLIP ViT-H/14 vision tower (width 1280,
+    32 layers, head dim 80, erf-GELU) + the 23-layer text tower (width 1024), Guide.embeds with
+    the Linear image guidance vs oracle.guide_ref on the CPU.  The reference hard-codes CLIP-L
+    (utils.py:24-25), so the oracle is the target here.'''
+    from flexdiffuse_amd import Guide, build
+    from flexdiffuse_amd.clip import CLIPModel
+    from flexdiffuse_amd.tokenizer import SyntheticTokenizer
+    from oracle import guide_ref
+    from test_oracle_clip import synth_image
+    sds = build.synthetic_state_dicts('sd21', seed=0, parts=('clip',))
+    _, _, ccfg = build.configs('sd21')
+    assert ccfg.vision.hidden_size == 1280 and ccfg.text.num_hidden_layers == 23
+    clip = CLIPModel(sds['clip'], ccfg, dev)
+    tok = SyntheticTokenizer(vocab_size=ccfg.text.vocab_size)
+    img = synth_image(2, 512, 512)
+    kw = dict(guide_threshold_mult=0.0, guide_clustered=0.0, guide_linear=(0.0, 0.5), guide_max_guidance=0.5)
+    g = Guide(clip, tok, device='cuda')
+    got = g.embeds(prompt='a castle on a hill at sunset', guide=img, **kw)
+    ref = guide_ref.GuideRef(sds['clip'], ccfg, tok)
+    want = ref.embeds(prompt='a castle on a hill at sunset', guide=img, **kw)
+    e_img = relerr(g.encoder.image(img), ref.image(img))
+    e = relerr(got, want)
+    print(f'c5 ViT-H/14 guide: image tokens rel err {e_img:.4f}, guided embeddings rel err {e:.4f}')
+    assert got.shape == (1, 77, 1024) and e_img < 3e-2 and e < 3e-2
+    assert float((want - ref.prompt('a castle on a hill at sunset')).abs().max()) > 0.1   # guidance acted
+
+
+def test_vae_decode_in_sample_chunks_and_large_gemm_fallback(mini, dev):
+    '''Tensors past the 2 GiB reach of the LDS-DMA buffer descriptors: the VAE decodes a large
+    batch in sample chunks (forced here with a tiny limit) with the same result as one pass, and
+    fd_gemm_f16 re-dispatches an operand >= 2 GiB to the register-staged 4-wave kernel instead
+    of failing.'''
+    from flexdiffuse_amd import ops
+    sds, pipe, clip, tok, _ = mini
+    z = torch.randn((5, 4, 8, 8), generator=torch.Generator().manual_seed(4)).to(dev)
+    whole = pipe.vae.decode(z).sample
+    try:
+        pipe.vae.decode_chunk_elems = 2 * 16 * 16 * 64        # two samples per chunk
+        parts = pipe.vae.decode(z).sample
+    finally:
+        del pipe.vae.decode_chunk_elems
+    assert parts.shape == whole.shape and relerr(parts, whole) < 2e-3
+    # A of 2.1 GiB (M x K fp16): 16 waves / LDS-DMA cannot address it, the 4-wave kernel can
+    M, K, N = 1 << 20, 1088, 64
+    a = torch.empty((M, K), dtype=torch.float16, device=dev)
+    a.normal_(generator=None)
+    w = ops.prep_linear(torch.randn((N, K), generator=torch.Generator().manual_seed(1)) * 0.05, None, dev)
+    out = ops.gemm(a, w)
+    rows = torch.tensor([0, 12345, M // 2 + 7, M - 1], device=dev)
+    want = a[rows].float() @ w.w[:, :K].float().t()
+    assert float((out[rows].float() - want).abs().max()) < 2e-2 * float(want.abs().max())
