@@ -56,6 +56,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int tap_fast;  // conv: tap-fastest K order (see k_gemm_f16_dma)
     int bias_lds;  // stage the tile's bias through LDS (FD_GEMM_BIAS_LDS=0 reads it from global memory)
+    int fast_epi;  // 1: full tiles may take gemm_epilogue_fast (rows 16-byte aligned, split_k == 1)
     int split_k;   // > 1: blockIdx.y owns a K slice and stores fp32 partials to `ws`
     float* ws;     // [split_k][M][N] fp32
 };
@@ -102,6 +103,110 @@ __device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
 #endif
 }
 
+// Lean epilogue for the common case: a tile that lies completely inside [M][N], fp16 output with
+// 16-byte-aligned rows, bias / per-sample bias already staged in LDS by the main loop, activation
+// and residual fixed at COMPILE time.  The generic epilogue below handles every flag at run time
+// inside the per-fragment loops; hipcc turns that into ~1200 executed instructions per wave and
+// tile (exec-mask branches and bounds tests per fragment, integer divisions for the sample index,
+// SGPR spills through v_readlane, a `switch (act)` per element), i.e. 6-8 us per tile on EVERY
+// launch -- more than the whole K loop of the K <= 640 transformer projections.  Here a fragment
+// costs one v_fma per element (alpha and the summed biases), the activation, the optional
+// residual add, a packed convert and half a 16-byte store.
+template <int MI, int NI, int ACT, bool RES>
+__device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&acc)[MI][NI], int row0,
+                                                   int col0, int coll, int fq, int z,
+                                                   lds_cfloat bias_tile, lds_cfloat bias2_tile) {
+    typedef const __attribute__((address_space(3))) floatx4* lds_cf4;
+    const int pcol = (fq & 1) * 16 + (fq >> 1) * 8;   // column of this lane's paired 16-byte store
+    if constexpr (ACT == FD_ACT_GEGLU) {
+        // interleaved weight rows: even fragment = value, odd fragment = gate; output width N/2
+        constexpr int NP = NI / 2;
+        floatx4 bv[NP], bg[NP];
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+            bv[jp] = floatx4{0.f, 0.f, 0.f, 0.f};
+            bg[jp] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (bias_tile) {
+                bv[jp] = *reinterpret_cast<lds_cf4>(bias_tile + coll + jp * 32 + fq * 4);
+                bg[jp] = *reinterpret_cast<lds_cf4>(bias_tile + coll + jp * 32 + 16 + fq * 4);
+            }
+        }
+        half_t* Cb = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC + (size_t)row0 * g.ldc + (col0 >> 1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            half_t* Crow = Cb + (size_t)i * 16 * g.ldc;
+            half4 og[NP];
+#pragma unroll
+            for (int jp = 0; jp < NP; ++jp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaf(acc[i][2 * jp][r], g.alpha, bv[jp][r]);
+                    const float gt = fmaf(acc[i][2 * jp + 1][r], g.alpha, bg[jp][r]);
+                    og[jp][r] = (half_t)(v * gelu_fast(gt));
+                }
+#pragma unroll
+            for (int jp = 0; jp < NP; jp += 2) {
+                if (jp + 1 < NP) {
+                    const u32x2 x = __builtin_bit_cast(u32x2, og[jp]);
+                    const u32x2 y = __builtin_bit_cast(u32x2, og[jp + 1 < NP ? jp + 1 : jp]);
+                    unsigned x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+                    swap16(x0, y0);
+                    swap16(x1, y1);
+                    *reinterpret_cast<u32x4*>(Crow + jp * 16 + pcol) = u32x4{x0, x1, y0, y1};
+                } else {
+                    *reinterpret_cast<half4*>(Crow + jp * 16 + fq * 4) = og[jp];
+                }
+            }
+        }
+        return;
+    } else {
+        floatx4 bb[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            bb[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (bias_tile) bb[j] = *reinterpret_cast<lds_cf4>(bias_tile + coll + j * 16 + fq * 4);
+            if (bias2_tile) bb[j] += *reinterpret_cast<lds_cf4>(bias2_tile + coll + j * 16 + fq * 4);
+        }
+        half_t* Cb = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC + (size_t)row0 * g.ldc + col0;
+        const half_t* Rb = RES ? g.res + (size_t)z * g.strideRes + (size_t)row0 * g.ldr + col0 + fq * 4 : nullptr;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            half_t* Crow = Cb + (size_t)i * 16 * g.ldc;
+            half4 rr[RES ? NI : 1];
+            if constexpr (RES) {
+                const half_t* Rrow = Rb + (size_t)i * 16 * g.ldr;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) rr[j] = *reinterpret_cast<const half4*>(Rrow + j * 16);
+            }
+            half4 oh[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = fmaf(acc[i][j][r], g.alpha, bb[j][r]);
+                    if constexpr (ACT == FD_ACT_SILU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+                    if constexpr (ACT == FD_ACT_QUICK_GELU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
+                    if constexpr (ACT == FD_ACT_GELU) v = gelu_fast(v);
+                    if constexpr (RES) v += (float)rr[j][r];
+                    oh[j][r] = (half_t)v;
+                }
+#pragma unroll
+            for (int j = 0; j < NI; j += 2) {
+                if (j + 1 < NI) {
+                    const u32x2 x = __builtin_bit_cast(u32x2, oh[j]);
+                    const u32x2 y = __builtin_bit_cast(u32x2, oh[j + 1 < NI ? j + 1 : j]);
+                    unsigned x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+                    swap16(x0, y0);
+                    swap16(x1, y1);
+                    *reinterpret_cast<u32x4*>(Crow + j * 16 + pcol) = u32x4{x0, x1, y0, y1};
+                } else {
+                    *reinterpret_cast<half4*>(Crow + j * 16 + fq * 4) = oh[j];
+                }
+            }
+        }
+    }
+}
+
 // Fused epilogue shared by the register-staged and the LDS-DMA main loops.
 template <int BM, int BN, bool TRANS, int WM = 2, int WN = 2>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
@@ -140,6 +245,36 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
             }
         }
         return;
+    }
+    // ---- fast path: full tile, fp16 rows, LDS-staged biases (see gemm_epilogue_fast) -------
+    if constexpr (!TRANS) {
+        if (g.fast_epi && !g.out_f32 && m0 + BM <= g.M && n0 + BN <= g.N && (!g.bias || bias_tile) &&
+            (!g.bias2 || bias2_tile)) {
+            const int row0 = m0 + wm * WTM + fr, col0 = n0 + wn * WTN, coll = wn * WTN;
+            if (g.act == FD_ACT_GEGLU) {
+                if constexpr (NI % 2 == 0) {
+                    gemm_epilogue_fast<MI, NI, FD_ACT_GEGLU, false>(g, acc, row0, col0, coll, fq, z, bias_tile, bias2_tile);
+                    return;
+                }
+            } else if (g.res) {
+                if (g.act == FD_ACT_NONE) {
+                    gemm_epilogue_fast<MI, NI, FD_ACT_NONE, true>(g, acc, row0, col0, coll, fq, z, bias_tile, bias2_tile);
+                    return;
+                }
+            } else if (g.act == FD_ACT_NONE) {
+                gemm_epilogue_fast<MI, NI, FD_ACT_NONE, false>(g, acc, row0, col0, coll, fq, z, bias_tile, bias2_tile);
+                return;
+            } else if (g.act == FD_ACT_SILU) {
+                gemm_epilogue_fast<MI, NI, FD_ACT_SILU, false>(g, acc, row0, col0, coll, fq, z, bias_tile, bias2_tile);
+                return;
+            } else if (g.act == FD_ACT_QUICK_GELU) {
+                gemm_epilogue_fast<MI, NI, FD_ACT_QUICK_GELU, false>(g, acc, row0, col0, coll, fq, z, bias_tile, bias2_tile);
+                return;
+            } else if (g.act == FD_ACT_GELU) {
+                gemm_epilogue_fast<MI, NI, FD_ACT_GELU, false>(g, acc, row0, col0, coll, fq, z, bias_tile, bias2_tile);
+                return;
+            }
+        }
     }
     // ---- epilogue -----------------------------------------------------------------------
     if (TRANS) {
@@ -1062,6 +1197,7 @@ static bool g_use_dma = getenv("FD_GEMM_NO_DMA") == nullptr;
 static int g_vae15 = getenv("FD_GEMM_VAE15") ? atoi(getenv("FD_GEMM_VAE15")) : 1;
 static int g_tap_fast = getenv("FD_CONV_TAPFAST") ? atoi(getenv("FD_CONV_TAPFAST")) : 1;   // 1: 256x320 tile, 2: every conv tile
 static int g_bias_lds = getenv("FD_GEMM_BIAS_LDS") ? atoi(getenv("FD_GEMM_BIAS_LDS")) : 1;
+static int g_fast_epi = getenv("FD_GEMM_FAST_EPI") ? atoi(getenv("FD_GEMM_FAST_EPI")) : 1;   // 0: generic epilogue only (A/B)
 // 0 = never, 1 = short-K GEMMs only (default), 2 = always
 static int g_persist_mode = getenv("FD_GEMM_PERSIST") ? atoi(getenv("FD_GEMM_PERSIST")) : 1;
 
@@ -1279,6 +1415,8 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                      FD_ESHAPE, "fd_gemm_f16: split_k=%d not possible for this problem", best_split);
     if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7 || best_tile == 9 || best_tile == 12 || best_tile == 13 || best_tile == 16)) best_tile = 1;
     g.split_k = best_split;
+    g.fast_epi = g_fast_epi && best_split == 1 && !g.out_f32 && (g.ldc & 7) == 0 && (!g.res || (g.ldr & 3) == 0) &&
+                 (g.act != FD_ACT_GEGLU || (g.ldc & 7) == 0);
     g.tap_fast = g.mode == MODE_CONV && (g_tap_fast == 2 || (g_tap_fast == 1 && best_tile == 16));
     fd_prof_begin(FD_FAMILY_GEMM, st, flops);
     switch (best_tile) {
