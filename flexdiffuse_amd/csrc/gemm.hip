@@ -56,7 +56,6 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int tap_fast;  // conv: tap-fastest K order (see k_gemm_f16_dma)
     int bias_lds;  // stage the tile's bias through LDS (FD_GEMM_BIAS_LDS=0 reads it from global memory)
-    int fast_epi;  // 1: full tiles may take gemm_epilogue_fast (rows 16-byte aligned, split_k == 1)
     int split_k;   // > 1: blockIdx.y owns a K slice and stores fp32 partials to `ws`
     float* ws;     // [split_k][M][N] fp32
 };
@@ -111,8 +110,12 @@ __device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
 // SGPR spills through v_readlane, a `switch (act)` per element), i.e. 6-8 us per tile on EVERY
 // launch -- more than the whole K loop of the K <= 640 transformer projections.  Here a fragment
 // costs one v_fma per element (alpha and the summed biases), the activation, the optional
-// residual add, a packed convert and half a 16-byte store.
-template <int MI, int NI, int ACT, bool RES>
+// residual add, a packed convert and half a 16-byte store.  It is a COMPILE-time choice of the
+// kernel (template parameter EPI of k_gemm_f16_dma / _dmap: 0 generic, 1 plain, 2 + residual,
+// 3 GEGLU): with both epilogues inlined in one kernel the 16-wave persistent kernels (128-VGPR
+// cap) spill ~500 bytes per lane to scratch and run 2x slower.  The host picks EPI != 0 only when
+// every tile of the launch is full and the biases are LDS-staged (launch_epi).
+template <int MI, int NI, int ACT, bool RES, bool B2>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&acc)[MI][NI], int row0,
                                                    int col0, int coll, int fq, int z,
                                                    lds_cfloat bias_tile, lds_cfloat bias2_tile) {
@@ -124,12 +127,11 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
         floatx4 bv[NP], bg[NP];
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
-            bv[jp] = floatx4{0.f, 0.f, 0.f, 0.f};
-            bg[jp] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (bias_tile) {
-                bv[jp] = *reinterpret_cast<lds_cf4>(bias_tile + coll + jp * 32 + fq * 4);
-                bg[jp] = *reinterpret_cast<lds_cf4>(bias_tile + coll + jp * 32 + 16 + fq * 4);
-            }
+            // the bias tile is ALWAYS valid here (zeros when the GEMM has no bias: the kernels stage
+            // it through a zero-length buffer descriptor): a `if (bias)` around these reads makes
+            // hipcc carry the whole array through phi copies and spill it
+            bv[jp] = *reinterpret_cast<lds_cf4>(bias_tile + coll + jp * 32 + fq * 4);
+            bg[jp] = *reinterpret_cast<lds_cf4>(bias_tile + coll + jp * 32 + 16 + fq * 4);
         }
         half_t* Cb = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC + (size_t)row0 * g.ldc + (col0 >> 1);
 #pragma unroll
@@ -157,15 +159,17 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
                     *reinterpret_cast<half4*>(Crow + jp * 16 + fq * 4) = og[jp];
                 }
             }
+            // one row block at a time: left alone the scheduler interleaves all MI blocks for ILP,
+            // runs out of the 128 VGPRs of a 16-wave workgroup and spills hundreds of dwords
+            __builtin_amdgcn_sched_barrier(0);
         }
         return;
     } else {
         floatx4 bb[NI];
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            bb[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (bias_tile) bb[j] = *reinterpret_cast<lds_cf4>(bias_tile + coll + j * 16 + fq * 4);
-            if (bias2_tile) bb[j] += *reinterpret_cast<lds_cf4>(bias2_tile + coll + j * 16 + fq * 4);
+            bb[j] = *reinterpret_cast<lds_cf4>(bias_tile + coll + j * 16 + fq * 4);
+            if constexpr (B2) bb[j] += *reinterpret_cast<lds_cf4>(bias2_tile + coll + j * 16 + fq * 4);
         }
         half_t* Cb = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC + (size_t)row0 * g.ldc + col0;
         const half_t* Rb = RES ? g.res + (size_t)z * g.strideRes + (size_t)row0 * g.ldr + col0 + fq * 4 : nullptr;
@@ -203,6 +207,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
                     *reinterpret_cast<half4*>(Crow + j * 16 + fq * 4) = oh[j];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);   // see the GEGLU branch
         }
     }
 }
@@ -245,36 +250,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
             }
         }
         return;
-    }
-    // ---- fast path: full tile, fp16 rows, LDS-staged biases (see gemm_epilogue_fast) -------
-    if constexpr (!TRANS) {
-        if (g.fast_epi && !g.out_f32 && m0 + BM <= g.M && n0 + BN <= g.N && (!g.bias || bias_tile) &&
-            (!g.bias2 || bias2_tile)) {
-            const int row0 = m0 + wm * WTM + fr, col0 = n0 + wn * WTN, coll = wn * WTN;
-            if (g.act == FD_ACT_GEGLU) {
-                if constexpr (NI % 2 == 0) {
-                    gemm_epilogue_fast<MI, NI, FD_ACT_GEGLU, false>(g, acc, row0, col0, coll, fq, z, bias_tile, bias2_tile);
-                    return;
-                }
-            } else if (g.res) {
-                if (g.act == FD_ACT_NONE) {
-                    gemm_epilogue_fast<MI, NI, FD_ACT_NONE, true>(g, acc, row0, col0, coll, fq, z, bias_tile, bias2_tile);
-                    return;
-                }
-            } else if (g.act == FD_ACT_NONE) {
-                gemm_epilogue_fast<MI, NI, FD_ACT_NONE, false>(g, acc, row0, col0, coll, fq, z, bias_tile, bias2_tile);
-                return;
-            } else if (g.act == FD_ACT_SILU) {
-                gemm_epilogue_fast<MI, NI, FD_ACT_SILU, false>(g, acc, row0, col0, coll, fq, z, bias_tile, bias2_tile);
-                return;
-            } else if (g.act == FD_ACT_QUICK_GELU) {
-                gemm_epilogue_fast<MI, NI, FD_ACT_QUICK_GELU, false>(g, acc, row0, col0, coll, fq, z, bias_tile, bias2_tile);
-                return;
-            } else if (g.act == FD_ACT_GELU) {
-                gemm_epilogue_fast<MI, NI, FD_ACT_GELU, false>(g, acc, row0, col0, coll, fq, z, bias_tile, bias2_tile);
-                return;
-            }
-        }
     }
     // ---- epilogue -----------------------------------------------------------------------
     if (TRANS) {
@@ -674,7 +649,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
 // by the buffer descriptor's bounds check (an offset past num_records reads 0), so there is
 // no select or branch on the load path.  The K-tile offset rides in the scalar soffset, so
 // per-lane address math only runs when the filter tap changes.
-template <int BM, int BN, bool CONV, int WM, bool TRANS = false, int NS = 2, int WN = 2>
+template <int BM, int BN, bool CONV, int WM, bool TRANS = false, int NS = 2, int WN = 2, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsigned a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses device-only builtins (host pass sees a stub)
     constexpr int NW = WN * WM;                 // waves: WM along M x WN along N
@@ -705,9 +680,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     // this tile's bias -> LDS (4 B per lane, 64 columns per wave instruction; zeros past N),
     // ahead of the first K-tile so that it lands with it
     float* bias_s = reinterpret_cast<float*>(smem + NS * STAGE);
-    if (g.bias && g.bias_lds) {
+    // EPI != 0 (lean epilogue): both bias tiles are always staged -- through a zero-length
+    // descriptor (every read returns 0) when the GEMM has no bias / no per-sample bias -- so the
+    // epilogue reads them without a branch.
+    if ((g.bias && g.bias_lds) || EPI != 0) {
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)g.bias, 0, (unsigned)((g.N + 3) & ~3) * 4u, 0x00020000);
+            (void*)(g.bias ? (const void*)g.bias : (const void*)g.W), 0, g.bias ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
         if (wave * 64 + lane < BN)   // lanes past the tile would spill into the next LDS buffer
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(bias_s + wave * 64), 4,
                                                      (unsigned)(n0 + wave * 64 + lane) * 4u, 0, 0, 0);
@@ -715,9 +693,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     // per-sample bias (ResBlock time embedding): one row when the whole tile lies in one sample
     const int b_first = m0 / g.rows_per_batch;
     const bool b2_staged = g.bias2 && g.bias_lds && (min(m0 + BM, g.M) - 1) / g.rows_per_batch == b_first;
-    if (b2_staged) {
+    if (b2_staged || EPI != 0) {
         const __amdgpu_buffer_rsrc_t rsB2 = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(g.bias2 + (size_t)b_first * g.ldb2), 0, (unsigned)((g.N + 3) & ~3) * 4u, 0x00020000);
+            (void*)(b2_staged ? (const void*)(g.bias2 + (size_t)b_first * g.ldb2) : (const void*)g.W), 0,
+            b2_staged ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
         if (wave * 64 + lane < BN)   // lanes past the tile would spill into the next LDS buffer
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(bias_s + BN + wave * 64), 4,
                                                      (unsigned)(n0 + wave * 64 + lane) * 4u, 0, 0, 0);
@@ -933,13 +912,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
         }
     }
 #undef GEMM_DMA_TILE
-    gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
-                                         b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr);
+    if constexpr (EPI == 0)
+        gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
+                                             b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr);
+    else
+        gemm_epilogue_fast<MI, NI, EPI == 3 ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, true>(
+            g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN));
 #endif
 }
 
 // Persistent variant of the LDS-DMA loop (used for short K loops).
-template <int BM, int BN, bool CONV, int WM, bool TRANS = false, int WN = 2>
+template <int BM, int BN, bool CONV, int WM, bool TRANS = false, int WN = 2, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, unsigned a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)  // body uses device-only builtins (host pass sees a stub)
     constexpr int NW = WN * WM;                 // waves: WM along M x WN along N
@@ -1139,8 +1122,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
                 __syncthreads();
             }
         }
-        gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z,
-                                             (g.bias && g.bias_lds) ? (lds_cfloat)(bias_s + bias_par * BN) : (lds_cfloat) nullptr);
+        if constexpr (EPI == 0)
+            gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z,
+                                                 (g.bias && g.bias_lds) ? (lds_cfloat)(bias_s + bias_par * BN) : (lds_cfloat) nullptr);
+        else
+            gemm_epilogue_fast<MI, NI, EPI == 3 ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, false>(
+                g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z,
+                (lds_cfloat)(bias_s + bias_par * BN), (lds_cfloat) nullptr);
         bias_par ^= 1;
         t = t_next;
     }
@@ -1201,7 +1189,7 @@ static int g_fast_epi = getenv("FD_GEMM_FAST_EPI") ? atoi(getenv("FD_GEMM_FAST_E
 // 0 = never, 1 = short-K GEMMs only (default), 2 = always
 static int g_persist_mode = getenv("FD_GEMM_PERSIST") ? atoi(getenv("FD_GEMM_PERSIST")) : 1;
 
-template <int BM, int BN, bool TRANS, bool CONV, int WM = 2, int NS = 2, int WN = 2>
+template <int BM, int BN, bool TRANS, bool CONV, int WM = 2, int NS = 2, int WN = 2, int EPI = 0>
 static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     g.tiles_m = fd_cdiv(g.M, BM);
     g.tiles_n = fd_cdiv(g.N, BN);
@@ -1215,10 +1203,10 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     if (g_use_dma && a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull) {
         static bool configured = false;
         if (!configured && lds > 64 * 1024) {
-            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV, WM, TRANS, NS, WN>),
+            FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV, WM, TRANS, NS, WN, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if constexpr (BN != 320)   // the 256x320 tile has no persistent form (it would spill)
-                FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS, WN>),
+                FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS, WN, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
@@ -1229,20 +1217,26 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         const int nkt = (g.K + BK - 1) / BK / g.split_k;
         const bool persistent = NS == 2 && BN != 320 && (g_persist_mode == 2 ||
                                 (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots));
+        if constexpr (EPI != 0) {
+            // the persistent loop does not stage the per-sample bias: generic epilogue there
+            if (persistent && g.bias2) return launch_mode<BM, BN, TRANS, CONV, WM, NS, WN, 0>(g, batch, st);
+        }
         if (persistent) {
             if constexpr (BN != 320) {
                 dim3 pgrid(g.tiles_m * g.tiles_n > slots ? slots : g.tiles_m * g.tiles_n, g.split_k, batch);
-                hipLaunchKernelGGL((k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS, WN>), pgrid, dim3(64 * WM * WN), lds,
+                hipLaunchKernelGGL((k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS, WN, EPI>), pgrid, dim3(64 * WM * WN), lds,
                                    st, g, (unsigned)a_bytes, (unsigned)w_bytes);
             }
         } else {
-            hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV, WM, TRANS, NS, WN>), grid, dim3(64 * WM * WN), lds, st, g,
+            hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV, WM, TRANS, NS, WN, EPI>), grid, dim3(64 * WM * WN), lds, st, g,
                                (unsigned)a_bytes, (unsigned)w_bytes);
         }
         FD_CHECK_LAUNCH("k_gemm_f16_dma");
         return FD_OK;
     }
-    if constexpr (WM != 2 || WN != 2) {
+    if constexpr (EPI != 0) {
+        return launch_mode<BM, BN, TRANS, CONV, WM, NS, WN, 0>(g, batch, st);
+    } else if constexpr (WM != 2 || WN != 2) {
         fd_set_error("fd_gemm_f16: 8-wave tiles need the LDS-DMA path (tensor < 2 GiB)");
         return FD_ESHAPE;
     } else {
@@ -1258,10 +1252,33 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     }
 }
 
-template <int BM, int BN, bool TRANS, int WM = 2, int NS = 2, int WN = 2>
+template <int BM, int BN, bool TRANS, int WM = 2, int NS = 2, int WN = 2, int EPI = 0>
 static int launch(GemmArgs& g, int batch, hipStream_t st) {
-    return g.mode == MODE_CONV ? launch_mode<BM, BN, TRANS, true, WM, NS, WN>(g, batch, st)
-                               : launch_mode<BM, BN, TRANS, false, WM, NS, WN>(g, batch, st);
+    return g.mode == MODE_CONV ? launch_mode<BM, BN, TRANS, true, WM, NS, WN, EPI>(g, batch, st)
+                               : launch_mode<BM, BN, TRANS, false, WM, NS, WN, EPI>(g, batch, st);
+}
+
+// Picks the lean epilogue (gemm_epilogue_fast) when every tile of the launch is full, the output
+// rows are 16-byte aligned fp16, the biases are staged in LDS and the activation is one the lean
+// form was instantiated for.  ALLOW: bit e set = EPI e exists for this tile (1 plain, 2 residual,
+// 3 GEGLU); everything else runs the generic epilogue.
+template <int BM, int BN, int WM, int NS, int WN, int ALLOW>
+static int launch_epi(GemmArgs& g, int batch, hipStream_t st) {
+    const bool full = g_fast_epi && g.split_k == 1 && !g.out_f32 && !g.trans_out && g.bias_lds &&
+                      g.M % BM == 0 && g.N % BN == 0 && (g.ldc & 7) == 0 &&
+                      (!g.bias2 || g.rows_per_batch % BM == 0);
+    if (full) {
+        if constexpr ((ALLOW & 8) != 0 && (BN / WN / 16) % 2 == 0) {
+            if (g.act == FD_ACT_GEGLU) return launch<BM, BN, false, WM, NS, WN, 3>(g, batch, st);
+        }
+        if constexpr ((ALLOW & 4) != 0) {
+            if (g.act == FD_ACT_NONE && g.res && (g.ldr & 3) == 0) return launch<BM, BN, false, WM, NS, WN, 2>(g, batch, st);
+        }
+        if constexpr ((ALLOW & 2) != 0) {
+            if (g.act == FD_ACT_NONE && !g.res) return launch<BM, BN, false, WM, NS, WN, 1>(g, batch, st);
+        }
+    }
+    return launch<BM, BN, false, WM, NS, WN, 0>(g, batch, st);
 }
 
 extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
@@ -1415,8 +1432,6 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                      FD_ESHAPE, "fd_gemm_f16: split_k=%d not possible for this problem", best_split);
     if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7 || best_tile == 9 || best_tile == 12 || best_tile == 13 || best_tile == 16)) best_tile = 1;
     g.split_k = best_split;
-    g.fast_epi = g_fast_epi && best_split == 1 && !g.out_f32 && (g.ldc & 7) == 0 && (!g.res || (g.ldr & 3) == 0) &&
-                 (g.act != FD_ACT_GEGLU || (g.ldc & 7) == 0);
     g.tap_fast = g.mode == MODE_CONV && (g_tap_fast == 2 || (g_tap_fast == 1 && best_tile == 16));
     fd_prof_begin(FD_FAMILY_GEMM, st, flops);
     switch (best_tile) {
@@ -1426,15 +1441,15 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         case 5: rc = launch<256, 160, false, 4>(g, batch, st); break;
         case 6: rc = launch<256, 128, false, 4>(g, batch, st); break;
         case 7: rc = launch<256, 160, false, 4, 3>(g, batch, st); break;
-        case 9: rc = launch<128, 160, false, 4>(g, batch, st); break;    // 8 waves, 32x80 wave tiles
-        case 10: rc = launch<128, 128, false, 4>(g, batch, st); break;
+        case 9: rc = launch_epi<128, 160, 4, 2, 2, 6>(g, batch, st); break;    // 8 waves, 32x80 wave tiles
+        case 10: rc = launch_epi<128, 128, 4, 2, 2, 14>(g, batch, st); break;
         case 11: rc = launch<128, 64, false, 4>(g, batch, st); break;
-        case 12: rc = launch<128, 160, false, 8>(g, batch, st); break;   // 16 waves, 16x80 wave tiles
-        case 13: rc = launch<256, 160, false, 8>(g, batch, st); break;   // 16 waves, 32x80 wave tiles
-        case 14: rc = launch<256, 128, false, 8>(g, batch, st); break;   // 16 waves, 32x64 wave tiles
+        case 12: rc = launch_epi<128, 160, 8, 2, 2, 6>(g, batch, st); break;   // 16 waves, 16x80 wave tiles
+        case 13: rc = launch_epi<256, 160, 8, 2, 2, 6>(g, batch, st); break;   // 16 waves, 32x80 wave tiles
+        case 14: rc = launch_epi<256, 128, 8, 2, 2, 14>(g, batch, st); break;   // 16 waves, 32x64 wave tiles
         case 8: rc = launch<256, 128, false, 4, 3>(g, batch, st); break;
-        case 15: rc = launch<256, 256, false, 4, 2, 4>(g, batch, st); break;  // 16 waves, 64x64 wave tiles
-        case 16: rc = launch<256, 320, false, 4, 2, 4>(g, batch, st); break;  // 16 waves, 64x80 wave tiles
+        case 15: rc = launch_epi<256, 256, 4, 2, 4, 14>(g, batch, st); break;  // 16 waves, 64x64 wave tiles
+        case 16: rc = launch_epi<256, 320, 4, 2, 4, 6>(g, batch, st); break;  // 16 waves, 64x80 wave tiles
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }
     if (rc == FD_OK && g.split_k > 1) {
