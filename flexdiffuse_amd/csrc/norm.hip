@@ -398,7 +398,9 @@ extern "C" int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const f
     nchunk = fd_cdiv(HW, ppc);
     const size_t lds1 = (size_t)PL * C * 2 * sizeof(float);
     FD_CHECK_ARG(lds1 <= 64 * 1024, FD_ESHAPE, "fd_groupnorm_nhwc_f16: stats LDS too large");
-    const double bytes = (double)B * HW * C * 6.0;
+    // priced at SURVEY 8(d)'s ALGORITHMIC 4 B/element (fp16 read + write); the streaming pair really
+    // moves 6 B/element (the statistics pass reads x once more, mostly from the Infinity Cache)
+    const double bytes = (double)B * HW * C * 4.0;
     fd_prof_begin(FD_FAMILY_GROUPNORM, st, bytes);
     hipLaunchKernelGGL(k_gn_stats, dim3(nchunk, B), dim3(threads), lds1, st, (const half_t*)x, ws,
                        HW, C, G, PL, ppc, ldx);

@@ -39,4 +39,4 @@ for (B,HW,C) in [(16,4096,320),(16,4096,960),(16,1024,640),(16,256,1280),(16,64,
     x = ops.Act(torch.randn((B*HW,C),device=dev).half(),B,HW,1)
     g = torch.ones(C,device=dev); b=torch.zeros(C,device=dev)
     ms = timeit(lambda: ops.groupnorm(x,g,b,32,1e-5,True), n=10)
-    print(f'B={B} HW={HW} C={C}: {ms*1e3:.1f} us  {B*HW*C*6/ms/1e6:.1f} GB/s (6B/elem)')
+    print(f'B={B} HW={HW} C={C}: {ms*1e3:.1f} us  {B*HW*C*4/ms/1e6:.1f} GB/s (4B/elem)')
