@@ -293,8 +293,11 @@ __global__ __launch_bounds__(64 * NW, (DQK <= 96 ? 2 : 1)) void k_attention(Attn
 #ifndef ATT_VPRE
 #define ATT_VPRE 0
 #endif
+#ifndef ATT_W8_MINW
+#define ATT_W8_MINW 8   // waves per SIMD the d <= 48 kernel is compiled for (8: 64 VGPRs, 6: 80 VGPRs)
+#endif
 template <int DQK, int DV, bool PRE, bool ONES>
-__global__ __launch_bounds__(512, (DV <= 3 ? 8 : DQK <= 96 ? 2 : 1)) void k_attention_w8(AttnArgs a) {
+__global__ __launch_bounds__(512, (DV <= 3 ? ATT_W8_MINW : DQK <= 96 ? 2 : 1)) void k_attention_w8(AttnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KS = DQK / 32;
     constexpr int NT = 512;
@@ -355,27 +358,32 @@ __global__ __launch_bounds__(512, (DV <= 3 ? 8 : DQK <= 96 ? 2 : 1)) void k_atte
 
     // per-thread constant load offsets / LDS store addresses
     unsigned kvo[KLD], vvo[VLD];
-    int krow[KLD], vkey[VLD], kst[KLD], vst[VLD];
+    // LDS store offsets of this thread's K chunk (low 16 bits) and V^T chunk (high 16 bits) in ONE
+    // register: at the 64-VGPR budget of 8 waves/SIMD the separate V offset was spilled to scratch
+    // and reloaded (scratch_load + vmcnt(0)) in every K/V tile iteration
+    unsigned kvst[KLD > VLD ? KLD : VLD];
+    static_assert(2 * (KBYTES + VBYTES) < 65536 + 65536, "LDS offsets must fit 16 bits");
     bool vones[VLD], vlive[VLD];
 #pragma unroll
     for (int i = 0; i < KLD; ++i) {
         const int e = tid + NT * i;
         const int row = e / KCH, c = e - row * KCH;
-        krow[i] = row;
         kvo[i] = (e < 64 * KCH && c * 8 < d) ? (unsigned)(row * a.ldk + c * 8) * 2u : OOB;
-        kst[i] = row * KSTR + c * 16;
+        kvst[i] = (unsigned)(row * KSTR + c * 16);
     }
+#pragma unroll
+    for (int i = KLD; i < VLD; ++i) kvst[i] = 0u;
 #pragma unroll
     for (int i = 0; i < VLD; ++i) {
         const int e = tid + NT * i;
         const int row = e >> 3, c = e & 7;
-        vkey[i] = c * 8;
         vvo[i] = (e < VROWS * 8 && row < d) ? (unsigned)(row * a.ldvt + c * 8) * 2u : OOB;
         vones[i] = ONES && row == d;
         vlive[i] = e < VROWS * 8 && row < d;
         const int grp = c >> 2, cc = c & 3;
         const int pos = grp * 32 + (cc & 1) * 16 + (cc >> 1) * 4;  // halfs (see k_attention)
-        vst[i] = KBYTES + row * VSTR + pos * 2;
+        kvst[i] |= (unsigned)(KBYTES + row * VSTR + pos * 2) << 16;
+        asm volatile("" : "+v"(kvst[i]));   // opaque: keeps the optimizer from un-packing the two halves again
     }
 
     u32x4 rk[KLD], rv[VLD];
@@ -389,11 +397,11 @@ __global__ __launch_bounds__(512, (DV <= 3 ? 8 : DQK <= 96 ? 2 : 1)) void k_atte
                 rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, vvo[i], key0 * 2, 0);      \
         } else { /* ragged last tile: rows / key chunks past the end read zero */             \
             _Pragma("unroll") for (int i = 0; i < KLD; ++i) {                                 \
-                const unsigned vo = (key0 + krow[i] < a.Nk) ? kvo[i] + (unsigned)key0 * a.ldk * 2u : OOB; \
+                const unsigned vo = (key0 + (tid + NT * i) / KCH < a.Nk) ? kvo[i] + (unsigned)key0 * a.ldk * 2u : OOB; /* row recomputed: rare path */ \
                 rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, vo, 0, 0);                 \
             }                                                                                 \
             _Pragma("unroll") for (int i = 0; i < VLD; ++i) {                                 \
-                const unsigned vo = (key0 + vkey[i] < nk8) ? vvo[i] + (unsigned)key0 * 2u : OOB; \
+                const unsigned vo = (key0 + ((tid + NT * i) & 7) * 8 < nk8) ? vvo[i] + (unsigned)key0 * 2u : OOB; \
                 rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, vo, 0, 0);                 \
             }                                                                                 \
         }                                                                                     \
@@ -403,11 +411,11 @@ __global__ __launch_bounds__(512, (DV <= 3 ? 8 : DQK <= 96 ? 2 : 1)) void k_atte
         char* sb = sKV + (BUF) * (KBYTES + VBYTES);                                           \
         _Pragma("unroll") for (int i = 0; i < KLD; ++i)                                       \
             if (KLD * NT == 64 * KCH || tid + NT * i < 64 * KCH)                              \
-                *reinterpret_cast<u32x4*>(sb + kst[i]) = rk[i];                               \
+                *reinterpret_cast<u32x4*>(sb + (kvst[i] & 0xffffu)) = rk[i];                               \
         _Pragma("unroll") for (int i = 0; i < VLD; ++i)                                       \
             if (vlive[i]) {                                                                   \
-                *reinterpret_cast<u32x2*>(sb + vst[i]) = u32x2{rv[i][0], rv[i][1]};           \
-                *reinterpret_cast<u32x2*>(sb + vst[i] + 16) = u32x2{rv[i][2], rv[i][3]};      \
+                *reinterpret_cast<u32x2*>(sb + (kvst[i] >> 16)) = u32x2{rv[i][0], rv[i][1]};  \
+                *reinterpret_cast<u32x2*>(sb + (kvst[i] >> 16) + 16) = u32x2{rv[i][2], rv[i][3]}; \
             }                                                                                 \
     }
 
@@ -421,8 +429,8 @@ __global__ __launch_bounds__(512, (DV <= 3 ? 8 : DQK <= 96 ? 2 : 1)) void k_atte
 #pragma unroll
             for (int buf = 0; buf < 2; ++buf) {
                 char* sb = sKV + buf * (KBYTES + VBYTES);
-                *reinterpret_cast<u32x2*>(sb + vst[i]) = u32x2{w, w};
-                *reinterpret_cast<u32x2*>(sb + vst[i] + 16) = u32x2{w, w};
+                *reinterpret_cast<u32x2*>(sb + (kvst[i] >> 16)) = u32x2{w, w};
+                *reinterpret_cast<u32x2*>(sb + (kvst[i] >> 16) + 16) = u32x2{w, w};
             }
         }
     }
