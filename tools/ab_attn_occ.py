@@ -4,7 +4,8 @@ import sys, os, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if len(sys.argv) == 1:
-    libs = [('w8', None), ('w6', 'tools/_variants/lib_attw6.so'), ('w4', 'tools/_variants/lib_attw4.so')]
+    libs = [('w8', None)] + [(os.path.basename(f)[4:-3], 'tools/_variants/' + os.path.basename(f))
+                             for f in sorted(__import__('glob').glob(os.path.join(ROOT, 'tools/_variants/lib_att*.so')))]
     for name, lib in libs * 2:
         env = dict(os.environ)
         if lib: env['FD_LIB_PATH'] = os.path.join(ROOT, lib)
