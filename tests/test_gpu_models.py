@@ -601,18 +601,26 @@ def test_sd21_c5_size_unet_properties(dev):
 
 
 def test_sd15_c4_size_img2img_properties(dev):
-    """BASELINE configs[3] sizes: SD1.5 img2img at 768x768 (96x96 latents), 50 DDIM steps,
-    strength 0.6 => 30 UNet evaluations from timesteps[20:] (pipeline/flex.py:193-221).  Too
-    large for the CPU oracle; checked through size-independent properties: the executed
-    timestep list, output range / shape, and bit-identical reruns from the same generator."""
-    from flexdiffuse_amd import SimpleGuide, build
+    """BASELINE configs[3]: SD1.5 img2img + image-guidance combo at 768x768 (96x96 latents), batch 4
+    per GPU, 50 DDIM steps, strength 0.6 => 30 UNet evaluations from timesteps[20:]
+    (pipeline/flex.py:193-221), embeddings from Guide.embeds with a guide image (Linear).  Too
+    large for the CPU oracle; checked through size-independent properties: the executed timestep
+    list, output range / shape, bit-identical reruns from the same generator, and that both the
+    prompts and the guide image change the result."""
+    from flexdiffuse_amd import Guide, SimpleGuide, build
     from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from test_oracle_clip import synth_image
     sds = build.synthetic_state_dicts('sd15', seed=0)
     pipe, clip, tok = build.build_models(sds, 'sd15', dev, vae_encoder=True)
     enc = CLIPEncoder(clip, tok)
     g = torch.Generator().manual_seed(6)
     image = (torch.rand((1, 3, 768, 768), generator=g) * 2 - 1)
-    emb = enc.prompt(['a castle on a hill', 'a bowl of fruit'])
+    prompts = ['a castle on a hill', 'a bowl of fruit', 'a red fox in snow', 'a city street at night']
+    guide = Guide(clip, tok, device='cuda')
+    kw = dict(guide_threshold_mult=0.0, guide_clustered=0.0, guide_linear=(0.0, 0.5), guide_max_guidance=0.5)
+    emb = guide.embeds(prompt=prompts, guide=synth_image(2, 512, 512), **kw)
+    emb_plain = guide.embeds(prompt=prompts)
+    assert emb.shape == (4, 77, 768) and float((emb - emb_plain).abs().max()) > 0.1   # the guide acted
     seen = []
     inner = pipe.unet.forward_nhwc
 
@@ -626,14 +634,17 @@ def test_sd15_c4_size_img2img_properties(dev):
             out = pipe(guide=SimpleGuide(enc, pipe.unet, 8.0, 50, emb), init_image=image, strength=0.6,
                        generator=torch.Generator('cpu').manual_seed(3), output_type='np')
             outs.append(np.asarray(out.images))
+        plain = pipe(guide=SimpleGuide(enc, pipe.unet, 8.0, 50, emb_plain), init_image=image, strength=0.6,
+                     generator=torch.Generator('cpu').manual_seed(3), output_type='np')
     finally:
         pipe.unet.forward_nhwc = inner
     want_t = [int(t) for t in pipe.scheduler.timesteps[20:]]
-    assert len(want_t) == 30 and seen == want_t + want_t
-    assert outs[0].shape == (2, 768, 768, 3)
+    assert len(want_t) == 30 and seen == want_t * 3
+    assert outs[0].shape == (4, 768, 768, 3)
     assert np.isfinite(outs[0]).all() and outs[0].min() >= 0.0 and outs[0].max() <= 1.0
     assert np.array_equal(outs[0], outs[1])           # deterministic kernels, same generator
-    assert float(np.abs(outs[0][0] - outs[0][1]).mean()) > 1e-3   # the two prompts differ
+    assert float(np.abs(outs[0][0] - outs[0][1]).mean()) > 1e-3   # the prompts differ
+    assert float(np.abs(outs[0] - np.asarray(plain.images)).mean()) > 1e-4   # the guide image matters
 
 
 # ---- the reference's own back-half code, replayed on the device -------------------------------
