@@ -330,13 +330,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                 const int j = 2 * jp;
                 const int nb0 = n0 + wn * WTN + j * 16 + fq * 4;
                 float v[4], gt[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[i][j][r] * g.alpha;
-                    gt[r] = acc[i][j + 1][r] * g.alpha;
-                }
+                floatx4 bb = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
                 if (g.bias && nb0 + 16 < g.N) {
-                    floatx4 bb, bg;
                     if (bias_tile) {
                         bb = *reinterpret_cast<const __attribute__((address_space(3))) floatx4*>(bias_tile + (nb0 - n0));
                         bg = *reinterpret_cast<const __attribute__((address_space(3))) floatx4*>(bias_tile + (nb0 - n0) + 16);
@@ -344,11 +339,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                         bb = *reinterpret_cast<const floatx4*>(g.bias + nb0);
                         bg = *reinterpret_cast<const floatx4*>(g.bias + nb0 + 16);
                     }
+                }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] += bb[r];
-                        gt[r] += bg[r];
-                    }
+                for (int r = 0; r < 4; ++r) {   // one fma, as in gemm_epilogue_fast
+                    v[r] = fmaf(acc[i][j][r], g.alpha, bb[r]);
+                    gt[r] = fmaf(acc[i][j + 1][r], g.alpha, bg[r]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) og[jp][r] = (half_t)(v[r] * gelu_fast(gt[r]));
@@ -395,24 +390,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
         for (int j = 0; j < NI; ++j) {
             const int nb0 = n0 + wn * WTN + j * 16 + fq * 4;
             if (nb0 >= g.N) continue;
+            // same arithmetic as gemm_epilogue_fast (bias + per-sample bias first, then ONE fma with
+            // alpha), so a tensor computed partly by full and partly by edge tiles -- or by both
+            // kernels at different batch sizes -- rounds identically
             float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
+            floatx4 bsum = {0.f, 0.f, 0.f, 0.f};
             if (g.bias) {
-                floatx4 bb;
-                if (bias_tile) bb = *reinterpret_cast<const __attribute__((address_space(3))) floatx4*>(bias_tile + (nb0 - n0));
-                else bb = *reinterpret_cast<const floatx4*>(g.bias + nb0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bb[r];
+                if (bias_tile) bsum = *reinterpret_cast<const __attribute__((address_space(3))) floatx4*>(bias_tile + (nb0 - n0));
+                else bsum = *reinterpret_cast<const floatx4*>(g.bias + nb0);
             }
             if (g.bias2) {
                 floatx4 bb;
                 if (bias2_tile) bb = *reinterpret_cast<const __attribute__((address_space(3))) floatx4*>(bias2_tile + (nb0 - n0));
                 else if constexpr (BATCH) bb = rb2[j];
                 else bb = *reinterpret_cast<const floatx4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bb[r];
+                bsum += bb;
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[i][j][r], g.alpha, bsum[r]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], g.act);
             if (g.res) {
@@ -1151,16 +1146,17 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs g) {
                 *reinterpret_cast<const float4*>(g.ws + ((size_t)s * g.M + m) * g.N + nb0);
             a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
         }
-        float v[4] = {a.x * g.alpha, a.y * g.alpha, a.z * g.alpha, a.w * g.alpha};
+        float bs[4] = {0.f, 0.f, 0.f, 0.f};   // bias + per-sample bias first, then one fma (as the GEMM epilogues)
         if (g.bias) {
             const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb0);
-            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            bs[0] = bb.x; bs[1] = bb.y; bs[2] = bb.z; bs[3] = bb.w;
         }
         if (g.bias2) {
             const int b = m / g.rows_per_batch;
             const float4 bb = *reinterpret_cast<const float4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
-            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            bs[0] += bb.x; bs[1] += bb.y; bs[2] += bb.z; bs[3] += bb.w;
         }
+        float v[4] = {fmaf(a.x, g.alpha, bs[0]), fmaf(a.y, g.alpha, bs[1]), fmaf(a.z, g.alpha, bs[2]), fmaf(a.w, g.alpha, bs[3])};
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], g.act);
         if (g.res) {
@@ -1407,6 +1403,14 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         if (best_split == 1 && best_tile == 14 && g.N % 256 == 0 && g_vae15 && (t15 >= 1024 || t15 % 256 == 0))
             best_tile = 15;
     }
+    // 16x16-resolution transformer GEMMs (M = 4096, N = 1280, K >= 1280): 256 tiles of 128x160, one per
+    // CU, each a 20..80-deep K loop whose DMA round trip (not the MFMAs) sets the pace -- a third LDS
+    // stage (two K-tiles in flight) gives -10 % at K = 1280, -22 % at K = 2560 (vs 256x160 + split-K 2),
+    // -3 % at K = 5120 (tools/ab_ns3.py).  Convolutions and M >= 16 k lose with it (one workgroup per CU).
+    if (g.mode != MODE_CONV && n160 && g.M > 2048 && g.M <= 4096 && g.K >= 1280 && batch == 1) {
+        best_tile = 20;
+        best_split = 1;
+    }
     if (d->tile) best_tile = d->tile;
     if (d->split_k > 0) best_split = d->split_k;
     {
@@ -1430,7 +1434,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         FD_CHECK_ARG(!geglu && batch == 1 && g.N % 4 == 0 && g.ws &&
                          (size_t)best_split * g.M * g.N * 4 <= (size_t)d->workspace_bytes,
                      FD_ESHAPE, "fd_gemm_f16: split_k=%d not possible for this problem", best_split);
-    if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7 || best_tile == 9 || best_tile == 12 || best_tile == 13 || best_tile == 16)) best_tile = 1;
+    if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7 || best_tile == 9 || best_tile == 12 || best_tile == 13 || best_tile == 16 || best_tile == 20)) best_tile = 1;
     g.split_k = best_split;
     g.tap_fast = g.mode == MODE_CONV && (g_tap_fast == 2 || (g_tap_fast == 1 && best_tile == 16));
     fd_prof_begin(FD_FAMILY_GEMM, st, flops);
@@ -1450,6 +1454,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         case 8: rc = launch<256, 128, false, 4, 3>(g, batch, st); break;
         case 15: rc = launch_epi<256, 256, 4, 2, 4, 14>(g, batch, st); break;  // 16 waves, 64x64 wave tiles
         case 16: rc = launch_epi<256, 320, 4, 2, 4, 6>(g, batch, st); break;  // 16 waves, 64x80 wave tiles
+        case 20: rc = launch_epi<128, 160, 4, 3, 2, 6>(g, batch, st); break;   // tile 9 with 3 LDS stages
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }
     if (rc == FD_OK && g.split_k > 1) {

@@ -183,7 +183,9 @@ def test_unet_cfg_prefix_sharing_matches_replicated_batch(mini, dev):
     shared = pipe.unet.forward_nhwc(x.to(dev), 437, ctx.to(dev), rep=2)
     plain = pipe.unet.forward_nhwc(torch.cat([x, x]).to(dev), 437, ctx.to(dev), rep=1)
     assert shared.shape == plain.shape == (2 * B * h * h, 4)
-    assert float((shared - plain).abs().max()) <= 1e-3 * float(plain.abs().max())
+    # not bit-identical: the shared prefix runs its GEMMs at M = B*HW, the replicated batch at 2*B*HW, so
+    # tile / split-K choices (fp32 summation order) differ and an fp16 rounding can flip (1 ulp = 1e-3)
+    assert float((shared - plain).abs().max()) <= 2e-3 * float(plain.abs().max())
     want = unet_ref.unet_forward(sds['unet'], ucfg, torch.cat([x, x]), 437, ctx)
     got = shared.view(2 * B, h, h, 4).permute(0, 3, 1, 2)
     assert relerr(got, want) < 3e-2

@@ -4,8 +4,9 @@ import torch
 from flexdiffuse_amd import ops
 dev = torch.device('cuda:0')
 tiles = [int(t) for t in (sys.argv[1].split(',') if len(sys.argv) > 1 else '0,13,15')]
-def timeit(fn, n=10):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, n=60):
+    for _ in range(8): fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
@@ -14,9 +15,9 @@ def timeit(fn, n=10):
 shapes = [(16,64,320,320),(16,64,640,320),(16,64,960,320),(16,32,640,640),(16,32,1280,640),(16,32,1920,640),(16,16,1280,1280),(16,16,2560,1280),(16,8,2560,1280)]
 lin = [(65536,320,1280),(16384,640,2560),(4096,1280,5120)]
 res = {}
-for t in tiles:
+for t in tiles * 2:
     ops.FORCE_TILE = t
-    ops.FORCE_SPLIT = 1 if t else 0
+    ops.FORCE_SPLIT = (int(os.environ.get('AB_SPLIT', '1')) if t else 0)
     row = []
     for (B,H,Cin,Cout) in shapes:
         x = ops.Act(torch.randn((B*H*H,Cin), device=dev).half(), B,H,H)
