@@ -56,6 +56,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int tap_fast;  // conv: tap-fastest K order (see k_gemm_f16_dma)
     int bias_lds;  // stage the tile's bias through LDS (FD_GEMM_BIAS_LDS=0 reads it from global memory)
+    const float* ln_stats;  // LayerNorm fold: per row of A (rstd, -mean*rstd); bias2 = column sums of W, bias = folded bias
     int split_k;   // > 1: blockIdx.y owns a K slice and stores fp32 partials to `ws`
     float* ws;     // [split_k][M][N] fp32
 };
@@ -115,7 +116,7 @@ __device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
 // 3 GEGLU): with both epilogues inlined in one kernel the 16-wave persistent kernels (128-VGPR
 // cap) spill ~500 bytes per lane to scratch and run 2x slower.  The host picks EPI != 0 only when
 // every tile of the launch is full and the biases are LDS-staged (launch_epi).
-template <int MI, int NI, int ACT, bool RES, bool B2>
+template <int MI, int NI, int ACT, bool RES, bool B2, bool LNF = false>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&acc)[MI][NI], int row0,
                                                    int col0, int coll, int fq, int z,
                                                    lds_cfloat bias_tile, lds_cfloat bias2_tile) {
@@ -125,6 +126,14 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
         // interleaved weight rows: even fragment = value, odd fragment = gate; output width N/2
         constexpr int NP = NI / 2;
         floatx4 bv[NP], bg[NP];
+        floatx4 cv[LNF ? NP : 1], cg[LNF ? NP : 1];   // LayerNorm fold: column sums of the folded weights
+        if constexpr (LNF) {
+#pragma unroll
+            for (int jp = 0; jp < NP; ++jp) {
+                cv[jp] = *reinterpret_cast<lds_cf4>(bias2_tile + coll + jp * 32 + fq * 4);
+                cg[jp] = *reinterpret_cast<lds_cf4>(bias2_tile + coll + jp * 32 + 16 + fq * 4);
+            }
+        }
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
             // the bias tile is ALWAYS valid here (zeros when the GEMM has no bias: the kernels stage
@@ -138,12 +147,20 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
         for (int i = 0; i < MI; ++i) {
             half_t* Crow = Cb + (size_t)i * 16 * g.ldc;
             half4 og[NP];
+            floatx2 st = {g.alpha, 0.f};   // LNF: (rstd, -mean * rstd) of this lane's row
+            if constexpr (LNF) st = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)(row0 + i * 16));
 #pragma unroll
             for (int jp = 0; jp < NP; ++jp)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = fmaf(acc[i][2 * jp][r], g.alpha, bv[jp][r]);
-                    const float gt = fmaf(acc[i][2 * jp + 1][r], g.alpha, bg[jp][r]);
+                    float v, gt;
+                    if constexpr (LNF) {   // LN(x) W^T = rstd (x W'^T) - rstd mean colsum(W') + (b + beta W^T)
+                        v = fmaf(acc[i][2 * jp][r], st[0], fmaf(st[1], cv[jp][r], bv[jp][r]));
+                        gt = fmaf(acc[i][2 * jp + 1][r], st[0], fmaf(st[1], cg[jp][r], bg[jp][r]));
+                    } else {
+                        v = fmaf(acc[i][2 * jp][r], g.alpha, bv[jp][r]);
+                        gt = fmaf(acc[i][2 * jp + 1][r], g.alpha, bg[jp][r]);
+                    }
                     og[jp][r] = (half_t)(v * gelu_fast(gt));
                 }
 #pragma unroll
@@ -166,10 +183,12 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
         return;
     } else {
         floatx4 bb[NI];
+        floatx4 cs[LNF ? NI : 1];
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             bb[j] = *reinterpret_cast<lds_cf4>(bias_tile + coll + j * 16 + fq * 4);
-            if constexpr (B2) bb[j] += *reinterpret_cast<lds_cf4>(bias2_tile + coll + j * 16 + fq * 4);
+            if constexpr (LNF) cs[j] = *reinterpret_cast<lds_cf4>(bias2_tile + coll + j * 16 + fq * 4);
+            else if constexpr (B2) bb[j] += *reinterpret_cast<lds_cf4>(bias2_tile + coll + j * 16 + fq * 4);
         }
         half_t* Cb = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC + (size_t)row0 * g.ldc + col0;
         const half_t* Rb = RES ? g.res + (size_t)z * g.strideRes + (size_t)row0 * g.ldr + col0 + fq * 4 : nullptr;
@@ -183,11 +202,15 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
                 for (int j = 0; j < NI; ++j) rr[j] = *reinterpret_cast<const half4*>(Rrow + j * 16);
             }
             half4 oh[NI];
+            floatx2 st = {g.alpha, 0.f};
+            if constexpr (LNF) st = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)(row0 + i * 16));
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = fmaf(acc[i][j][r], g.alpha, bb[j][r]);
+                    float v;
+                    if constexpr (LNF) v = fmaf(acc[i][j][r], st[0], fmaf(st[1], cs[j][r], bb[j][r]));
+                    else v = fmaf(acc[i][j][r], g.alpha, bb[j][r]);
                     if constexpr (ACT == FD_ACT_SILU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
                     if constexpr (ACT == FD_ACT_QUICK_GELU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
                     if constexpr (ACT == FD_ACT_GELU) v = gelu_fast(v);
@@ -213,7 +236,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
 }
 
 // Fused epilogue shared by the register-staged and the LDS-DMA main loops.
-template <int BM, int BN, bool TRANS, int WM = 2, int WN = 2>
+template <int BM, int BN, bool TRANS, int WM = 2, int WN = 2, bool LN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                                               floatx4 (&acc)[BM / WM / 16][BN / WN / 16], int m0, int n0,
                                               int wm, int wn, int fr, int fq, int z,
@@ -270,10 +293,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                 else bn = g.bias[n];
             }
             half4 oh[MI];
+            if (LN && g.ln_stats) {
+                // LayerNorm fold on the transposed layout: the lane's 4 values of a fragment are 4
+                // consecutive ROWS m, each with its own (rstd, -mean * rstd)
+                const float csn = (n_ok && g.bias2) ? g.bias2[n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int mb = min(m0 + wm * WTM + i * 16 + fq * 4, g.M - 4 > 0 ? g.M - 4 : 0);
+                    const floatx4 s01 = *reinterpret_cast<const floatx4*>(g.ln_stats + 2 * (size_t)mb);
+                    const floatx4 s23 = *reinterpret_cast<const floatx4*>(g.ln_stats + 2 * (size_t)mb + 4);
+                    const float rs[4] = {s01[0], s01[2], s23[0], s23[2]}, mr[4] = {s01[1], s01[3], s23[1], s23[3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        oh[i][r] = (half_t)act_apply(fmaf(acc[i][j][r], rs[r], fmaf(mr[r], csn, bn)), g.act);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) oh[i][r] = (half_t)act_apply(acc[i][j][r] * g.alpha + bn, g.act);
+            }
 #pragma unroll
             for (int i = 0; i < MI; i += 2) {
                 const int mblk = m0 + wm * WTM + i * 16;           // 32-row block (wave-uniform)
@@ -340,10 +379,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                         bg = *reinterpret_cast<const floatx4*>(g.bias + nb0 + 16);
                     }
                 }
+                if (LN && g.ln_stats) {
+                    const floatx2 st = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)m);
+                    floatx4 cv = {0.f, 0.f, 0.f, 0.f}, cg = {0.f, 0.f, 0.f, 0.f};
+                    if (g.bias2 && nb0 + 16 < g.N) {
+                        cv = *reinterpret_cast<const floatx4*>(g.bias2 + nb0);
+                        cg = *reinterpret_cast<const floatx4*>(g.bias2 + nb0 + 16);
+                    }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {   // one fma, as in gemm_epilogue_fast
-                    v[r] = fmaf(acc[i][j][r], g.alpha, bb[r]);
-                    gt[r] = fmaf(acc[i][j + 1][r], g.alpha, bg[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = fmaf(acc[i][j][r], st[0], fmaf(st[1], cv[r], bb[r]));
+                        gt[r] = fmaf(acc[i][j + 1][r], st[0], fmaf(st[1], cg[r], bg[r]));
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {   // one fma, as in gemm_epilogue_fast
+                        v[r] = fmaf(acc[i][j][r], g.alpha, bb[r]);
+                        gt[r] = fmaf(acc[i][j + 1][r], g.alpha, bg[r]);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) og[jp][r] = (half_t)(v[r] * gelu_fast(gt[r]));
@@ -399,15 +452,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                 if (bias_tile) bsum = *reinterpret_cast<const __attribute__((address_space(3))) floatx4*>(bias_tile + (nb0 - n0));
                 else bsum = *reinterpret_cast<const floatx4*>(g.bias + nb0);
             }
+            floatx4 b2v = {0.f, 0.f, 0.f, 0.f};
             if (g.bias2) {
-                floatx4 bb;
-                if (bias2_tile) bb = *reinterpret_cast<const __attribute__((address_space(3))) floatx4*>(bias2_tile + (nb0 - n0));
-                else if constexpr (BATCH) bb = rb2[j];
-                else bb = *reinterpret_cast<const floatx4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
-                bsum += bb;
+                if (bias2_tile) b2v = *reinterpret_cast<const __attribute__((address_space(3))) floatx4*>(bias2_tile + (nb0 - n0));
+                else if constexpr (BATCH) b2v = rb2[j];
+                else b2v = *reinterpret_cast<const floatx4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
             }
+            if (LN && g.ln_stats) {   // LayerNorm fold (see gemm_epilogue_fast): bias2 carries colsum(W')
+                const floatx2 st = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)m);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[i][j][r], g.alpha, bsum[r]);
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[i][j][r], st[0], fmaf(st[1], b2v[r], bsum[r]));
+            } else {
+                bsum += b2v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[i][j][r], g.alpha, bsum[r]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], g.act);
             if (g.res) {
@@ -678,7 +737,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     // EPI != 0 (lean epilogue): both bias tiles are always staged -- through a zero-length
     // descriptor (every read returns 0) when the GEMM has no bias / no per-sample bias -- so the
     // epilogue reads them without a branch.
-    if ((g.bias && g.bias_lds) || EPI != 0) {
+    if ((g.bias && g.bias_lds) || (EPI != 0 && EPI != 7)) {
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(g.bias ? (const void*)g.bias : (const void*)g.W), 0, g.bias ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
         if (wave * 64 + lane < BN)   // lanes past the tile would spill into the next LDS buffer
@@ -688,7 +747,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     // per-sample bias (ResBlock time embedding): one row when the whole tile lies in one sample
     const int b_first = m0 / g.rows_per_batch;
     const bool b2_staged = g.bias2 && g.bias_lds && (min(m0 + BM, g.M) - 1) / g.rows_per_batch == b_first;
-    if (b2_staged || EPI != 0) {
+    if (b2_staged || (EPI != 0 && EPI != 7)) {
         const __amdgpu_buffer_rsrc_t rsB2 = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(b2_staged ? (const void*)(g.bias2 + (size_t)b_first * g.ldb2) : (const void*)g.W), 0,
             b2_staged ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
@@ -907,11 +966,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
         }
     }
 #undef GEMM_DMA_TILE
-    if constexpr (EPI == 0)
-        gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
-                                             b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr);
+    if constexpr (EPI == 0 || EPI == 7)   // 7: the generic epilogue with the LayerNorm fold compiled in
+        gemm_epilogue<BM, BN, TRANS, WM, WN, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
+                                                       b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr);
     else
-        gemm_epilogue_fast<MI, NI, EPI == 3 ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, true>(
+        gemm_epilogue_fast<MI, NI, (EPI == 3 || EPI == 6) ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, true, (EPI == 5 || EPI == 6)>(
             g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN));
 #endif
 }
@@ -944,10 +1003,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(g.bias ? g.bias : (const float*)g.W), 0, g.bias ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
     int bias_par = 0;
+    // EPI 5 / 6 (LayerNorm fold): the column sums of the folded weights (bias2, one row) ride along
+    const __amdgpu_buffer_rsrc_t rsB2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((EPI == 5 || EPI == 6) && g.bias2) ? (const void*)g.bias2 : (const void*)g.W), 0,
+        ((EPI == 5 || EPI == 6) && g.bias2) ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
 #define GEMM_DMA_BIAS(PAR)                                                                  \
-    if (wave * 64 + lane < BN)                                                               \
+    if (wave * 64 + lane < BN) {                                                             \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(bias_s + (PAR) * BN + wave * 64), 4, \
-                                                 (unsigned)(ld_n0 + wave * 64 + lane) * 4u, 0, 0, 0);
+                                                 (unsigned)(ld_n0 + wave * 64 + lane) * 4u, 0, 0, 0); \
+        if constexpr (EPI == 5 || EPI == 6)                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(bias_s + (2 + (PAR)) * BN + wave * 64), 4, \
+                                                     (unsigned)(ld_n0 + wave * 64 + lane) * 4u, 0, 0, 0); \
+    }
 
     const int rsub = lane >> 3;            // row inside the 8-row group
     const int ck = (lane & 7) ^ rsub;      // source chunk for this lane's LDS slot (swizzle)
@@ -1117,13 +1184,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
                 __syncthreads();
             }
         }
-        if constexpr (EPI == 0)
-            gemm_epilogue<BM, BN, TRANS, WM, WN>(g, acc, m0, n0, wm, wn, fr, fq, z,
-                                                 (g.bias && g.bias_lds) ? (lds_cfloat)(bias_s + bias_par * BN) : (lds_cfloat) nullptr);
+        if constexpr (EPI == 0 || EPI == 7)
+            gemm_epilogue<BM, BN, TRANS, WM, WN, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z,
+                                                           (g.bias && g.bias_lds) ? (lds_cfloat)(bias_s + bias_par * BN) : (lds_cfloat) nullptr);
         else
-            gemm_epilogue_fast<MI, NI, EPI == 3 ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, false>(
+            gemm_epilogue_fast<MI, NI, (EPI == 3 || EPI == 6) ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, false, (EPI == 5 || EPI == 6)>(
                 g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z,
-                (lds_cfloat)(bias_s + bias_par * BN), (lds_cfloat) nullptr);
+                (lds_cfloat)(bias_s + bias_par * BN), (lds_cfloat)(bias_s + (2 + bias_par) * BN));
         bias_par ^= 1;
         t = t_next;
     }
@@ -1189,7 +1256,7 @@ template <int BM, int BN, bool TRANS, bool CONV, int WM = 2, int NS = 2, int WN 
 static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     g.tiles_m = fd_cdiv(g.M, BM);
     g.tiles_n = fd_cdiv(g.N, BN);
-    const size_t lds = NS * (size_t)(BM + BN) * 128 + 2 * BN * sizeof(float);   // stages + bias tiles
+    const size_t lds = NS * (size_t)(BM + BN) * 128 + 4 * BN * sizeof(float);   // stages + 2 x (bias, bias2 / colsum) tiles
     dim3 grid(g.tiles_m * g.tiles_n, g.split_k, batch);
     // tensor extents for the buffer descriptors of the LDS-DMA loop (must fit 32 bits)
     const unsigned long long a_bytes =
@@ -1213,7 +1280,7 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         const int nkt = (g.K + BK - 1) / BK / g.split_k;
         const bool persistent = NS == 2 && BN != 320 && (g_persist_mode == 2 ||
                                 (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots));
-        if constexpr (EPI != 0) {
+        if constexpr (EPI >= 1 && EPI <= 3) {
             // the persistent loop does not stage the per-sample bias: generic epilogue there
             if (persistent && g.bias2) return launch_mode<BM, BN, TRANS, CONV, WM, NS, WN, 0>(g, batch, st);
         }
@@ -1229,6 +1296,10 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         }
         FD_CHECK_LAUNCH("k_gemm_f16_dma");
         return FD_OK;
+    }
+    if (g.ln_stats) {
+        fd_set_error("fd_gemm_f16: the LayerNorm fold needs the LDS-DMA path (tensor < 2 GiB, FD_GEMM_NO_DMA unset)");
+        return FD_ESHAPE;
     }
     if constexpr (EPI != 0) {
         return launch_mode<BM, BN, TRANS, CONV, WM, NS, WN, 0>(g, batch, st);
@@ -1257,12 +1328,25 @@ static int launch(GemmArgs& g, int batch, hipStream_t st) {
 // Picks the lean epilogue (gemm_epilogue_fast) when every tile of the launch is full, the output
 // rows are 16-byte aligned fp16, the biases are staged in LDS and the activation is one the lean
 // form was instantiated for.  ALLOW: bit e set = EPI e exists for this tile (1 plain, 2 residual,
-// 3 GEGLU); everything else runs the generic epilogue.
+// 3 GEGLU, 5 LayerNorm fold, 6 LayerNorm fold + GEGLU -- the last two for linear GEMMs only);
+// everything else runs the generic epilogue (which implements the same arithmetic at run time).
 template <int BM, int BN, int WM, int NS, int WN, int ALLOW>
 static int launch_epi(GemmArgs& g, int batch, hipStream_t st) {
     const bool full = g_fast_epi && g.split_k == 1 && !g.out_f32 && !g.trans_out && g.bias_lds &&
                       g.M % BM == 0 && g.N % BN == 0 && (g.ldc & 7) == 0 &&
                       (!g.bias2 || g.rows_per_batch % BM == 0);
+    if (full && g.ln_stats) {
+        if (g.mode != MODE_CONV && !g.res) {
+            if constexpr ((ALLOW & 64) != 0 && (BN / WN / 16) % 2 == 0) {
+                if (g.act == FD_ACT_GEGLU) return launch_mode<BM, BN, false, false, WM, NS, WN, 6>(g, batch, st);
+            }
+            if constexpr ((ALLOW & 32) != 0) {
+                if (g.act == FD_ACT_NONE) return launch_mode<BM, BN, false, false, WM, NS, WN, 5>(g, batch, st);
+            }
+        }
+        return launch_mode<128, 128, false, false, 2, 2, 2, 7>(g, batch, st);
+    }
+    if (g.ln_stats) return launch_mode<128, 128, false, false, 2, 2, 2, 7>(g, batch, st);
     if (full) {
         if constexpr ((ALLOW & 8) != 0 && (BN / WN / 16) % 2 == 0) {
             if (g.act == FD_ACT_GEGLU) return launch<BM, BN, false, WM, NS, WN, 3>(g, batch, st);
@@ -1325,6 +1409,18 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     if (g.bias) FD_CHECK_ARG((uintptr_t)g.bias % 16 == 0, FD_ESHAPE, "fd_gemm_f16: bias align");
     if (g.res) FD_CHECK_ARG(d->ldr % 4 == 0, FD_ESHAPE, "fd_gemm_f16: ldr must be a multiple of 4");
 
+    if (d->ln_stats) {
+        // LayerNorm fold: C = act(rstd_m (A W'^T)[m][n] - rstd_m mean_m colsum_n + bias_n), W' = W diag(gamma)
+        FD_CHECK_ARG(d->ln_colsum && !d->conv && !d->bias2 && !d->residual && !d->out_f32 && batch == 1 &&
+                         (d->act == FD_ACT_NONE || d->act == FD_ACT_GEGLU) && (d->alpha == 0.f || d->alpha == 1.f),
+                     FD_EINVAL, "fd_gemm_f16: ln_stats needs ln_colsum, a linear GEMM, no bias2 / residual / fp32 "
+                                "output, act NONE or GEGLU, alpha 1");
+        FD_CHECK_ARG(((uintptr_t)d->ln_stats % 16 == 0) && ((uintptr_t)d->ln_colsum % 16 == 0), FD_ESHAPE,
+                     "fd_gemm_f16: ln_stats / ln_colsum must be 16-byte aligned");
+        g.ln_stats = d->ln_stats;
+        g.bias2 = d->ln_colsum;   // one row for every sample: row stride 0
+        g.ldb2 = 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     const double flops = 2.0 * (double)d->M * d->N * d->K * batch;
     g.split_k = 1;
@@ -1333,7 +1429,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     int rc;
     if (d->trans_out) {
         fd_prof_begin(FD_FAMILY_GEMM, st, flops);
-        rc = launch<128, 64, true>(g, batch, st);
+        rc = g.ln_stats ? launch_mode<128, 64, true, false, 2, 2, 2, 7>(g, batch, st) : launch<128, 64, true>(g, batch, st);
         fd_prof_end(FD_FAMILY_GEMM, st);
         return rc;
     }
@@ -1413,6 +1509,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     }
     if (d->tile) best_tile = d->tile;
     if (d->split_k > 0) best_split = d->split_k;
+    if (g.ln_stats) best_split = 1;   // the split-K finish kernel does not know the fold
     {
         // The many-wave tiles exist only on the LDS-DMA path, whose buffer descriptors address a
         // tensor through 32-bit byte offsets (< 2 GiB).  Larger operands go to the register-staged
@@ -1438,6 +1535,13 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     g.split_k = best_split;
     g.tap_fast = g.mode == MODE_CONV && (g_tap_fast == 2 || (g_tap_fast == 1 && best_tile == 16));
     fd_prof_begin(FD_FAMILY_GEMM, st, flops);
+    if (g.ln_stats && !(best_tile == 9 || best_tile == 10 || (best_tile >= 12 && best_tile <= 16) || best_tile == 20)) {
+        // small problems: the generic epilogue with the fold compiled in (64x64 for few rows)
+        rc = best_tile == 4 ? launch_mode<64, 64, false, false, 2, 2, 2, 7>(g, batch, st)
+                            : launch_mode<128, 128, false, false, 2, 2, 2, 7>(g, batch, st);
+        fd_prof_end(FD_FAMILY_GEMM, st);
+        return rc;
+    }
     switch (best_tile) {
         case 2: rc = launch<128, 160, false>(g, batch, st); break;
         case 3: rc = launch<128, 64, false>(g, batch, st); break;
@@ -1445,16 +1549,16 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         case 5: rc = launch<256, 160, false, 4>(g, batch, st); break;
         case 6: rc = launch<256, 128, false, 4>(g, batch, st); break;
         case 7: rc = launch<256, 160, false, 4, 3>(g, batch, st); break;
-        case 9: rc = launch_epi<128, 160, 4, 2, 2, 6>(g, batch, st); break;    // 8 waves, 32x80 wave tiles
-        case 10: rc = launch_epi<128, 128, 4, 2, 2, 14>(g, batch, st); break;
+        case 9: rc = launch_epi<128, 160, 4, 2, 2, 38>(g, batch, st); break;    // 8 waves, 32x80 wave tiles
+        case 10: rc = launch_epi<128, 128, 4, 2, 2, 110>(g, batch, st); break;
         case 11: rc = launch<128, 64, false, 4>(g, batch, st); break;
-        case 12: rc = launch_epi<128, 160, 8, 2, 2, 6>(g, batch, st); break;   // 16 waves, 16x80 wave tiles
-        case 13: rc = launch_epi<256, 160, 8, 2, 2, 6>(g, batch, st); break;   // 16 waves, 32x80 wave tiles
-        case 14: rc = launch_epi<256, 128, 8, 2, 2, 14>(g, batch, st); break;   // 16 waves, 32x64 wave tiles
+        case 12: rc = launch_epi<128, 160, 8, 2, 2, 38>(g, batch, st); break;   // 16 waves, 16x80 wave tiles
+        case 13: rc = launch_epi<256, 160, 8, 2, 2, 38>(g, batch, st); break;   // 16 waves, 32x80 wave tiles
+        case 14: rc = launch_epi<256, 128, 8, 2, 2, 110>(g, batch, st); break;   // 16 waves, 32x64 wave tiles
         case 8: rc = launch<256, 128, false, 4, 3>(g, batch, st); break;
-        case 15: rc = launch_epi<256, 256, 4, 2, 4, 14>(g, batch, st); break;  // 16 waves, 64x64 wave tiles
-        case 16: rc = launch_epi<256, 320, 4, 2, 4, 6>(g, batch, st); break;  // 16 waves, 64x80 wave tiles
-        case 20: rc = launch_epi<128, 160, 4, 3, 2, 6>(g, batch, st); break;   // tile 9 with 3 LDS stages
+        case 15: rc = launch_epi<256, 256, 4, 2, 4, 110>(g, batch, st); break;  // 16 waves, 64x64 wave tiles
+        case 16: rc = launch_epi<256, 320, 4, 2, 4, 38>(g, batch, st); break;  // 16 waves, 64x80 wave tiles
+        case 20: rc = launch_epi<128, 160, 4, 3, 2, 38>(g, batch, st); break;   // tile 9 with 3 LDS stages
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }
     if (rc == FD_OK && g.split_k > 1) {

@@ -415,7 +415,8 @@ extern "C" int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const f
 // ---------------------------------------------------------------------------------------
 // LayerNorm over the last dim: one wavefront per row, the row lives in registers, exact
 // two-pass statistics (mean, then sum of squared deviations) with wave shuffles.
-template <int VPL, int RPW>  // uint4 vectors per lane: C <= 512*VPL; RPW rows per wavefront
+template <int VPL, int RPW, bool STATS = false>  // uint4 vectors per lane: C <= 512*VPL; RPW rows per wavefront;
+// STATS: write (rstd, -mean * rstd) per row to y instead of the normalised row (LayerNorm fold of fd_gemm_f16)
 __global__ __launch_bounds__(256) void k_layernorm(const half_t* __restrict__ x, void* __restrict__ y,
                                                    const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, int rows, int C,
@@ -460,6 +461,10 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* __restrict__ x,
             }
         }
         const float rstd = rsqrtf(fd_wave_sum(sq) / (float)C + eps);
+        if constexpr (STATS) {
+            if (lane == 0) reinterpret_cast<float2*>(y)[row] = make_float2(rstd, -mean * rstd);
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = (lane + 64 * i) * 8;
@@ -505,6 +510,28 @@ extern "C" int fd_layernorm_f16(const void* x, void* y, const float* gamma, cons
         hipLaunchKernelGGL((k_layernorm<4, 1>), dim3(fd_cdiv(rows, 4)), dim3(256), 0, st, (const half_t*)x, y,
                            gamma, beta, rows, C, ldx, ldy, eps, out_f32);
     FD_CHECK_LAUNCH("k_layernorm");
+    return FD_OK;
+}
+
+extern "C" int fd_ln_row_stats_f16(const void* x, float* stats, int rows, int C, int ldx, float eps, void* stream) {
+    FD_CHECK_ARG(x && stats && rows > 0 && C > 0, FD_EINVAL, "fd_ln_row_stats_f16: args");
+    FD_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && C <= 2048, FD_ESHAPE,
+                 "fd_ln_row_stats_f16: C=%d must be a multiple of 8 and <= 2048", C);
+    hipStream_t st = (hipStream_t)stream;
+    const float* nul = nullptr;
+    if (C <= 512 && rows >= 8192)
+        hipLaunchKernelGGL((k_layernorm<1, 2, true>), dim3(fd_cdiv(rows, 8)), dim3(256), 0, st, (const half_t*)x,
+                           (void*)stats, nul, nul, rows, C, ldx, 0, eps, 0);
+    else if (C <= 512)
+        hipLaunchKernelGGL((k_layernorm<1, 1, true>), dim3(fd_cdiv(rows, 4)), dim3(256), 0, st, (const half_t*)x,
+                           (void*)stats, nul, nul, rows, C, ldx, 0, eps, 0);
+    else if (C <= 1024)
+        hipLaunchKernelGGL((k_layernorm<2, 1, true>), dim3(fd_cdiv(rows, 4)), dim3(256), 0, st, (const half_t*)x,
+                           (void*)stats, nul, nul, rows, C, ldx, 0, eps, 0);
+    else
+        hipLaunchKernelGGL((k_layernorm<4, 1, true>), dim3(fd_cdiv(rows, 4)), dim3(256), 0, st, (const half_t*)x,
+                           (void*)stats, nul, nul, rows, C, ldx, 0, eps, 0);
+    FD_CHECK_LAUNCH("k_layernorm<stats>");
     return FD_OK;
 }
 

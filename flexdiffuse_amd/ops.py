@@ -31,7 +31,7 @@ class fd_gemm_desc(ctypes.Structure):
                 ('batch_stride_a', c_int64), ('batch_stride_w', c_int64),
                 ('batch_stride_c', c_int64), ('batch_stride_res', c_int64),
                 ('tile', c_int32), ('split_k', c_int32), ('workspace', c_void_p),
-                ('workspace_bytes', c_int64)]
+                ('workspace_bytes', c_int64), ('ln_stats', c_void_p), ('ln_colsum', c_void_p)]
 
 
 class fd_attention_desc(ctypes.Structure):
@@ -60,6 +60,7 @@ class LinW:
     bias: Optional[torch.Tensor]
     N: int
     K: int
+    colsum: Optional[torch.Tensor] = None   # LayerNorm fold: fp32 [N] row sums of the gain-folded fp16 weights
 
 
 @dataclass
@@ -101,6 +102,34 @@ def prep_geglu(w: torch.Tensor, b: torch.Tensor, dev) -> LinW:
     bv, bg = b[:half].reshape(half // 16, 16), b[half:].reshape(half // 16, 16)
     bi = torch.stack([bv, bg], dim=1).reshape(n2)
     return prep_linear(wi, bi, dev)
+
+
+def prep_linear_ln(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, dev,
+                   geglu: bool = False) -> LinW:
+    '''Linear layer that consumes LayerNorm(x; gamma, beta), with the LayerNorm FOLDED into the GEMM
+    (fd_gemm_desc.ln_stats):  LN(x) W^T + b = rstd (x W'^T) - rstd mean colsum(W') + (b + W beta),
+    W' = W diag(gamma).  Host-side weight preparation only (done once at model construction).'''
+    w32, g32, be32 = w.float(), gamma.float(), beta.float()
+    wf = (w32 * g32[None, :]).half()                      # the fp16 weights the MFMAs will see
+    bias = w32 @ be32 + (b.float() if b is not None else 0.0)
+    colsum = wf.float().sum(dim=1)                        # of the ROUNDED weights: exact cancellation of the mean
+    if geglu:
+        n2, K = wf.shape
+        half = n2 // 2
+        il = lambda t: torch.stack([t[:half].reshape(half // 16, 16, -1), t[half:].reshape(half // 16, 16, -1)],
+                                   dim=1).reshape(n2, -1)
+        wf, bias, colsum = il(wf), il(bias[:, None])[:, 0], il(colsum[:, None])[:, 0]
+    lw = prep_linear(wf, bias, dev)
+    lw.colsum = _bias(colsum, dev)
+    return lw
+
+
+def ln_row_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    '''fp16 [rows][C] -> fp32 [rows][2] = (rstd, -mean * rstd) per row (one read of x).'''
+    rows, C = x.shape
+    out = _empty((rows, 2), torch.float32, x)
+    hip.call('fd_ln_row_stats_f16', x.data_ptr(), out.data_ptr(), rows, C, x.stride(0), eps, hip.stream())
+    return out
 
 
 def prep_conv(w: torch.Tensor, b: Optional[torch.Tensor], dev, cin_pad: int = 0) -> ConvW:
@@ -167,7 +196,7 @@ def _sched(d: 'fd_gemm_desc', dev: torch.device):
 def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
          bias2: Optional[torch.Tensor] = None, ld_bias2: int = 0, rows_per_sample: int = 0,
          out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0,
-         use_bias: bool = True) -> torch.Tensor:
+         use_bias: bool = True, ln_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     '''a [M][K] fp16 @ w[N][K]^T with fused epilogue -> [M][N] (GEGLU: [M][N/2]).'''
     M, K = a.shape
     assert a.dtype == torch.float16 and a.stride(1) == 1 and K == w.K, (a.shape, w.K)
@@ -186,13 +215,16 @@ def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[to
     d.rows_per_sample = rows_per_sample
     d.act, d.out_f32, d.alpha = act, int(out_f32), alpha
     d.batch = 1
+    if ln_stats is not None:      # `a` holds the un-normalised rows, `w` comes from prep_linear_ln
+        assert w.colsum is not None and ln_stats.shape == (M, 2)
+        d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), w.colsum.data_ptr()
     _sched(d, a.device)
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     return out
 
 
 def gemm_vt(a: torch.Tensor, w: LinW, B: int, rows_per_sample: int, ld: int,
-            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            out: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     '''V projection with a transposed store: returns V^T [B][N][ld] fp16 (pad columns zero).'''
     M, K = a.shape
     assert M == B * rows_per_sample and K == w.K
@@ -210,6 +242,9 @@ def gemm_vt(a: torch.Tensor, w: LinW, B: int, rows_per_sample: int, ld: int,
     d.rows_per_sample = rows_per_sample
     d.trans_out, d.trans_ld, d.trans_sample_stride = 1, ld, w.N * ld
     d.alpha, d.batch = 1.0, 1
+    if ln_stats is not None:
+        assert w.colsum is not None and ln_stats.shape == (M, 2)
+        d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), w.colsum.data_ptr()
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     return out
 

@@ -12,6 +12,7 @@ all 22 ResBlock time-embedding projections are one GEMM per step.
 '''
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional
 
@@ -56,15 +57,30 @@ class _Attn:
         self.q_pre = ops.attention_accepts_prescaled(d)
         qs = ops.QK_LOG2E * d ** -0.5 if self.q_pre else 1.0
         # self-attention q and k share their input: one GEMM with the weights stacked along N
-        self.qk1 = ops.prep_linear(torch.cat([wq.float() * qs, g(f'{tb}.attn1.to_k.weight').float()], 0),
-                                   None, dev)
-        self.v1 = ops.prep_linear(g(f'{tb}.attn1.to_v.weight'), None, dev)
+        # LayerNorm fold (default): the three LayerNorms of the block are not launched; their consumer GEMMs
+        # (q|k, v, cross q, GEGLU) read the un-normalised hidden states with gain-folded weights and apply
+        # (rstd, mean) per row in their epilogues (fd_gemm_desc.ln_stats; one statistics pass per LayerNorm).
+        # FD_UNET_LN_FOLD=0 keeps the separate LayerNorm kernels (A/B).
+        self.ln_fold = os.environ.get('FD_UNET_LN_FOLD', '1') != '0'
+        wqk = torch.cat([wq.float() * qs, g(f'{tb}.attn1.to_k.weight').float()], 0)
+        wq2 = g(f'{tb}.attn2.to_q.weight').float() * qs
+        if self.ln_fold:
+            (g1, b1), (g2, b2), (g3, b3) = [(g(f'{tb}.norm{i}.weight'), g(f'{tb}.norm{i}.bias')) for i in (1, 2, 3)]
+            self.qk1 = ops.prep_linear_ln(wqk, None, g1, b1, dev)
+            self.v1 = ops.prep_linear_ln(g(f'{tb}.attn1.to_v.weight'), None, g1, b1, dev)
+            self.q2 = ops.prep_linear_ln(wq2, None, g2, b2, dev)
+            self.ff1 = ops.prep_linear_ln(g(f'{tb}.ff.net.0.proj.weight'), g(f'{tb}.ff.net.0.proj.bias'), g3, b3, dev,
+                                          geglu=True)
+        else:
+            # self-attention q and k share their input: one GEMM with the weights stacked along N
+            self.qk1 = ops.prep_linear(wqk, None, dev)
+            self.v1 = ops.prep_linear(g(f'{tb}.attn1.to_v.weight'), None, dev)
+            self.q2 = ops.prep_linear(wq2, None, dev)
+            self.ff1 = ops.prep_geglu(g(f'{tb}.ff.net.0.proj.weight'), g(f'{tb}.ff.net.0.proj.bias'), dev)
         self.o1 = ops.prep_linear(g(f'{tb}.attn1.to_out.0.weight'), g(f'{tb}.attn1.to_out.0.bias'), dev)
-        self.q2 = ops.prep_linear(g(f'{tb}.attn2.to_q.weight').float() * qs, None, dev)
         self.k2 = ops.prep_linear(g(f'{tb}.attn2.to_k.weight'), None, dev)
         self.v2 = ops.prep_linear(g(f'{tb}.attn2.to_v.weight'), None, dev)
         self.o2 = ops.prep_linear(g(f'{tb}.attn2.to_out.0.weight'), g(f'{tb}.attn2.to_out.0.bias'), dev)
-        self.ff1 = ops.prep_geglu(g(f'{tb}.ff.net.0.proj.weight'), g(f'{tb}.ff.net.0.proj.bias'), dev)
         self.ff2 = ops.prep_linear(g(f'{tb}.ff.net.2.weight'), g(f'{tb}.ff.net.2.bias'), dev)
         self.C = self.q2.N
         self.ctx_kv = None  # (K [Be*L][C], V^T [Be][C][ldv]) of the cached text context
@@ -228,27 +244,37 @@ class UNet2DConditionModel():
         d = C // a.heads
         h = ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False)
         h = ops.gemm(h.t, a.proj_in)
-        n = ops.layernorm(h, *a.ln[0])
-        qk = ops.gemm(n, a.qk1)
+        if a.ln_fold:
+            st = ops.ln_row_stats(h)
+            qk = ops.gemm(h, a.qk1, ln_stats=st)
+            vt = ops.gemm_vt(h, a.v1, B, HW, (HW + 7) // 8 * 8, ln_stats=st)
+        else:
+            n = ops.layernorm(h, *a.ln[0])
+            qk = ops.gemm(n, a.qk1)
+            vt = ops.gemm_vt(n, a.v1, B, HW, (HW + 7) // 8 * 8)
         q, k = qk[:, :C], qk[:, C:]
-        vt = ops.gemm_vt(n, a.v1, B, HW, (HW + 7) // 8 * 8)
         o = ops.attention(q, k, vt, B, a.heads, HW, HW, d, q_prescaled=a.q_pre)
         h = ops.gemm(o, a.o1, residual=h)
-        n = ops.layernorm(h, *a.ln[1])
+        if a.ln_fold:
+            q2 = ops.gemm(h, a.q2, ln_stats=ops.ln_row_stats(h))
+        else:
+            q2 = ops.gemm(ops.layernorm(h, *a.ln[1]), a.q2)
         kc, vtc, L = a.ctx_kv
         xt = x.t
         if rep == 1:
-            o = ops.attention(ops.gemm(n, a.q2), kc, vtc, B, a.heads, HW, L, d, q_prescaled=a.q_pre)
+            o = ops.attention(q2, kc, vtc, B, a.heads, HW, L, d, q_prescaled=a.q_pre)
         else:
-            q2 = ops.gemm(n, a.q2)
             o = torch.empty((rep * B * HW, C), dtype=torch.float16, device=q2.device)
             for r in range(rep):
                 ops.attention(q2, kc[r * B * L:(r + 1) * B * L], vtc[r * B:(r + 1) * B], B, a.heads,
                               HW, L, d, q_prescaled=a.q_pre, out=o[r * B * HW:(r + 1) * B * HW])
             h, xt, B = h.repeat(rep, 1), xt.repeat(rep, 1), rep * B
         h = ops.gemm(o, a.o2, residual=h)
-        n = ops.layernorm(h, *a.ln[2])
-        h = ops.gemm(ops.gemm(n, a.ff1, act=ops.ACT_GEGLU), a.ff2, residual=h)
+        if a.ln_fold:
+            f = ops.gemm(h, a.ff1, act=ops.ACT_GEGLU, ln_stats=ops.ln_row_stats(h))
+        else:
+            f = ops.gemm(ops.layernorm(h, *a.ln[2]), a.ff1, act=ops.ACT_GEGLU)
+        h = ops.gemm(f, a.ff2, residual=h)
         return Act(ops.gemm(h, a.proj_out, residual=xt, out=out), B, x.H, x.W)
 
     # ---- forward ----------------------------------------------------------------------------

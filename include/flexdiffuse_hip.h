@@ -32,7 +32,7 @@ extern "C" {
 #define FD_ESHAPE (-2) /* unsupported shape / alignment */
 #define FD_EHIP (-3)   /* HIP runtime error */
 
-#define FD_ABI_VERSION 3
+#define FD_ABI_VERSION 4
 
 int fd_abi_version(void);
 const char* fd_last_error(void);
@@ -153,6 +153,15 @@ typedef struct fd_gemm_desc {
     int32_t tile, split_k;
     void* workspace;
     int64_t workspace_bytes;
+    /* LayerNorm folded into the GEMM (replaces the separate LayerNorm launch diffusers' BasicTransformerBlock
+     * runs before attn1 / attn2 / ff inside `unet(...)`, reference pipeline/guide.py:56-58).  A holds the
+     * UN-normalised rows x, W the weights pre-multiplied by the LayerNorm gain (W' = W diag(gamma), fp16),
+     * bias = b + W beta, ln_colsum[n] = sum_k W'[n][k] (of the fp16 values), ln_stats[m] = (rstd_m,
+     * -mean_m rstd_m) from fd_ln_row_stats_f16:
+     *   C[m][n] = act(rstd_m (x W'^T)[m][n] - rstd_m mean_m ln_colsum[n] + bias[n])  ==  act(LN(x) W^T + b).
+     * Linear GEMMs only; act NONE or GEGLU; works with trans_out.  NULL = off. */
+    const float* ln_stats;  /* fp32 [M][2] */
+    const float* ln_colsum; /* fp32 [N] */
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);
@@ -197,6 +206,9 @@ int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const float* gamma
 /* LayerNorm over the last dim of fp16 x [rows][ldx] -> fp16 (or fp32) y [rows][ldy]. */
 int fd_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int rows,
                      int C, int ldx, int ldy, float eps, int out_f32, void* stream);
+/* Per-row LayerNorm statistics of fp16 x [rows][ldx] (exact two-pass, fp32): stats[row] = (rstd,
+ * -mean * rstd) with rstd = 1 / sqrt(var + eps); consumed by fd_gemm_desc.ln_stats. */
+int fd_ln_row_stats_f16(const void* x, float* stats, int rows, int C, int ldx, float eps, void* stream);
 /* In-place softmax(scale * x) over the first N columns of fp16 x [rows][ld]. */
 int fd_softmax_rows_f16(void* x, int rows, int N, int ld, float scale, void* stream);
 

@@ -293,3 +293,70 @@ def test_gemm_bias_tiles_staged_in_lds(dev):
     outs = [ops.gemm(ad, wlp).float().cpu() for _ in range(4)]
     close(outs[0][:, :N], a.half().float() @ wl.half().float().T + bl, rtol=3e-3, atol=3e-2)
     assert all(torch.equal(outs[0], o) for o in outs)
+
+
+def _ln_ref(x, gamma, beta, w, b, eps=1e-5):
+    n = torch.nn.functional.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps)
+    return n @ w.float().t() + (b.float() if b is not None else 0.0)
+
+
+@pytest.mark.parametrize('M,N,K', [(65536, 320, 320), (2048, 640, 320), (16384, 640, 640), (4096, 1280, 1280),
+                                   (1024, 1280, 1280), (1000, 328, 320), (200, 320, 640)])
+def test_gemm_layernorm_fold(dev, M, N, K):
+    '''fd_gemm_desc.ln_stats: LayerNorm folded into the GEMM (gain folded into the weights, per-row
+    (rstd, -mean rstd) applied in the epilogue) == LayerNorm followed by the linear layer.  Rows get
+    a non-zero mean and spread so that the mean term matters; shapes cover the lean persistent /
+    non-persistent kernels (EPI 5), the 3-stage tile, the 64x64 tile and ragged generic tiles.'''
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn((M, K), generator=g) * (0.5 + torch.rand((M, 1), generator=g) * 2) +
+         torch.randn((M, 1), generator=g) * 1.5).half()
+    gamma = 1.0 + 0.3 * torch.randn(K, generator=g)
+    beta = 0.2 * torch.randn(K, generator=g)
+    w = torch.randn((N, K), generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    lw = ops.prep_linear_ln(w, b, gamma, beta, dev)
+    xd = x.to(dev)
+    st = ops.ln_row_stats(xd)
+    mean, var = x.float().mean(1), x.float().var(1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    assert torch.allclose(st[:, 0].cpu(), rstd, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(st[:, 1].cpu(), -mean * rstd, rtol=1e-5, atol=1e-5)
+    got = ops.gemm(xd, lw, ln_stats=st)[:, :N].float().cpu()
+    want = _ln_ref(x, gamma, beta, w, b)
+    assert float((got - want).abs().max()) < 2e-2 * float(want.abs().max()), (M, N, K)
+    # and against the unfused device path (LayerNorm kernel + plain GEMM): same tolerance class
+    n16 = ops.layernorm(xd, gamma.to(dev), beta.to(dev))
+    plain = ops.gemm(n16, ops.prep_linear(w, b, dev))[:, :N].float().cpu()
+    assert float((got - plain).abs().max()) < 2e-2 * float(want.abs().max())
+    assert float((got - want).abs().mean()) <= 1.5 * float((plain - want).abs().mean()) + 1e-4
+
+
+@pytest.mark.parametrize('M,C', [(16384, 320), (4096, 320), (1024, 640), (264, 320)])
+def test_gemm_layernorm_fold_geglu_and_transposed(dev, M, C):
+    '''The fold through the GEGLU epilogue (EPI 6 and the generic path) and through the transposed
+    (V^T) store.'''
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn((M, C), generator=g) * 1.3 + torch.randn((M, 1), generator=g)).half()
+    gamma = 1.0 + 0.3 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    w = torch.randn((8 * C, C), generator=g) * C ** -0.5
+    b = torch.randn(8 * C, generator=g) * 0.1
+    xd = x.to(dev)
+    st = ops.ln_row_stats(xd)
+    lw = ops.prep_linear_ln(w, b, gamma, beta, dev, geglu=True)
+    got = ops.gemm(xd, lw, act=ops.ACT_GEGLU, ln_stats=st).float().cpu()
+    h = _ln_ref(x, gamma, beta, w, b)
+    want = h[:, :4 * C] * torch.nn.functional.gelu(h[:, 4 * C:])
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) < 2e-2 * float(want.abs().max()), (M, C)
+    # transposed store: V^T [B][C][HW] of LN(x) Wv^T
+    B = 4 if M % 4 == 0 and (M // 4) % 8 == 0 else 1
+    HW = M // B
+    if HW % 8 == 0:
+        wv = torch.randn((C, C), generator=g) * C ** -0.5
+        lv = ops.prep_linear_ln(wv, None, gamma, beta, dev)
+        vt = ops.gemm_vt(xd, lv, B, HW, HW, ln_stats=st).float().cpu()
+        want_v = _ln_ref(x, gamma, beta, wv, None).view(B, HW, C).permute(0, 2, 1)
+        assert float((vt - want_v).abs().max()) < 2e-2 * float(want_v.abs().max())
