@@ -283,6 +283,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
         const bool vec_ok = (g.rows_per_batch & 7) == 0 && (g.ldt & 7) == 0 && (g.strideT & 7) == 0 &&
                             (g.strideC & 7) == 0;
         const int prow = (fq & 1) * 16 + (fq >> 1) * 8;
+        // LayerNorm fold: the lane's 4 values of a fragment are 4 consecutive ROWS m, each with its own
+        // (rstd, -mean * rstd); loaded once per row block, not per column fragment
+        float ln_rs[LN ? MI : 1][4], ln_mr[LN ? MI : 1][4];
+        if constexpr (LN) {
+            if (g.ln_stats) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int mb = min(m0 + wm * WTM + i * 16 + fq * 4, g.M - 4 > 0 ? g.M - 4 : 0);
+                    const floatx4 s01 = *reinterpret_cast<const floatx4*>(g.ln_stats + 2 * (size_t)mb);
+                    const floatx4 s23 = *reinterpret_cast<const floatx4*>(g.ln_stats + 2 * (size_t)mb + 4);
+                    ln_rs[i][0] = s01[0]; ln_mr[i][0] = s01[1]; ln_rs[i][1] = s01[2]; ln_mr[i][1] = s01[3];
+                    ln_rs[i][2] = s23[0]; ln_mr[i][2] = s23[1]; ln_rs[i][3] = s23[2]; ln_mr[i][3] = s23[3];
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int n = n0 + wn * WTN + j * 16 + fr;
@@ -294,19 +309,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
             }
             half4 oh[MI];
             if (LN && g.ln_stats) {
-                // LayerNorm fold on the transposed layout: the lane's 4 values of a fragment are 4
-                // consecutive ROWS m, each with its own (rstd, -mean * rstd)
+                // LayerNorm fold on the transposed layout (row statistics hoisted out of the n loop)
                 const float csn = (n_ok && g.bias2) ? g.bias2[n] : 0.f;
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int mb = min(m0 + wm * WTM + i * 16 + fq * 4, g.M - 4 > 0 ? g.M - 4 : 0);
-                    const floatx4 s01 = *reinterpret_cast<const floatx4*>(g.ln_stats + 2 * (size_t)mb);
-                    const floatx4 s23 = *reinterpret_cast<const floatx4*>(g.ln_stats + 2 * (size_t)mb + 4);
-                    const float rs[4] = {s01[0], s01[2], s23[0], s23[2]}, mr[4] = {s01[1], s01[3], s23[1], s23[3]};
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        oh[i][r] = (half_t)act_apply(fmaf(acc[i][j][r], rs[r], fmaf(mr[r], csn, bn)), g.act);
-                }
+                        oh[i][r] = (half_t)act_apply(fmaf(acc[i][j][r], ln_rs[i][r], fmaf(ln_mr[i][r], csn, bn)), g.act);
             } else {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
