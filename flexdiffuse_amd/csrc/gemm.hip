@@ -56,6 +56,8 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int tap_fast;  // conv: tap-fastest K order (see k_gemm_f16_dma)
     int bias_lds;  // stage the tile's bias through LDS (FD_GEMM_BIAS_LDS=0 reads it from global memory)
+    float* ln_stats_out;    // row statistics (rstd, -mean*rstd) of the OUTPUT rows, written by full-row tiles (N == BN)
+    float ln_eps;
     const float* ln_stats;  // LayerNorm fold: per row of A (rstd, -mean*rstd); bias2 = column sums of W, bias = folded bias
     int split_k;   // > 1: blockIdx.y owns a K slice and stores fp32 partials to `ws`
     float* ws;     // [split_k][M][N] fp32
@@ -116,10 +118,11 @@ __device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
 // 3 GEGLU): with both epilogues inlined in one kernel the 16-wave persistent kernels (128-VGPR
 // cap) spill ~500 bytes per lane to scratch and run 2x slower.  The host picks EPI != 0 only when
 // every tile of the launch is full and the biases are LDS-staged (launch_epi).
-template <int MI, int NI, int ACT, bool RES, bool B2, bool LNF = false>
+template <int MI, int NI, int ACT, bool RES, bool B2, bool LNF = false, bool STATS = false, int WN_ = 1>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&acc)[MI][NI], int row0,
                                                    int col0, int coll, int fq, int z,
-                                                   lds_cfloat bias_tile, lds_cfloat bias2_tile) {
+                                                   lds_cfloat bias_tile, lds_cfloat bias2_tile,
+                                                   float* xch = nullptr, int trow0 = 0, int wn = 0, int m0 = 0) {
     typedef const __attribute__((address_space(3))) floatx4* lds_cf4;
     const int pcol = (fq & 1) * 16 + (fq >> 1) * 8;   // column of this lane's paired 16-byte store
     if constexpr (ACT == FD_ACT_GEGLU) {
@@ -217,6 +220,23 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
                     if constexpr (RES) v += (float)rr[j][r];
                     oh[j][r] = (half_t)v;
                 }
+            if constexpr (STATS) {
+                // LayerNorm statistics of the rows this kernel WRITES (the tile spans the whole row:
+                // N == BN), from the fp16-rounded values the consumer will read: lane partial over its
+                // 4 * NI columns -> the 4 lanes of a row (xor 16, 32) -> one slot per wave in LDS
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float f = (float)oh[j][r];
+                        s1 += f;
+                        s2 = fmaf(f, f, s2);
+                    }
+                s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (fq == 0) *reinterpret_cast<floatx2*>(xch + ((trow0 + i * 16) * WN_ + wn) * 2) = floatx2{s1, s2};
+            }
 #pragma unroll
             for (int j = 0; j < NI; j += 2) {
                 if (j + 1 < NI) {
@@ -231,6 +251,29 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
                 }
             }
             __builtin_amdgcn_sched_barrier(0);   // see the GEGLU branch
+        }
+        if constexpr (STATS) {
+            // combine the WN_ wave slots of each row and finalise: one lane per row (waves with wn == 0)
+            __syncthreads();
+            if (wn == 0) {
+                const float inv_n = 1.0f / (float)g.N;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    if (fq != (i & 3)) continue;   // spread the MI row blocks over the 4 lane groups
+                    const int tr = trow0 + i * 16;
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WN_; ++w) {
+                        const floatx2 p = *reinterpret_cast<const floatx2*>(xch + (tr * WN_ + w) * 2);
+                        s1 += p[0];
+                        s2 += p[1];
+                    }
+                    const float mean = s1 * inv_n;
+                    const float var = fmaxf(fmaf(-mean, mean, s2 * inv_n), 0.f);
+                    const float rstd = rsqrtf(var + g.ln_eps);
+                    *reinterpret_cast<floatx2*>(g.ln_stats_out + 2 * (size_t)(m0 + tr)) = floatx2{rstd, -mean * rstd};
+                }
+            }
         }
     }
 }
@@ -978,6 +1021,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     if constexpr (EPI == 0 || EPI == 7)   // 7: the generic epilogue with the LayerNorm fold compiled in
         gemm_epilogue<BM, BN, TRANS, WM, WN, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
                                                        b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr);
+    else if constexpr (EPI == 8 || EPI == 9)   // lean + LayerNorm statistics of the written rows (N == BN); the
+        // exchange buffer reuses stage 0 (the K loop ended with a barrier: the stages are dead)
+        gemm_epilogue_fast<MI, NI, FD_ACT_NONE, EPI == 9, true, false, true, WN>(
+            g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN),
+            reinterpret_cast<float*>(smem), wm * WTM + fr, wn, m0);
     else
         gemm_epilogue_fast<MI, NI, (EPI == 3 || EPI == 6) ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, true, (EPI == 5 || EPI == 6)>(
             g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN));
@@ -1197,7 +1245,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
             gemm_epilogue<BM, BN, TRANS, WM, WN, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z,
                                                            (g.bias && g.bias_lds) ? (lds_cfloat)(bias_s + bias_par * BN) : (lds_cfloat) nullptr);
         else
-            gemm_epilogue_fast<MI, NI, (EPI == 3 || EPI == 6) ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, false, (EPI == 5 || EPI == 6)>(
+            gemm_epilogue_fast<MI, NI, (EPI == 3 || EPI == 6) ? FD_ACT_GEGLU : FD_ACT_NONE, (EPI == 2 || EPI == 9), false, (EPI == 5 || EPI == 6)>(
                 g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z,
                 (lds_cfloat)(bias_s + bias_par * BN), (lds_cfloat)(bias_s + (2 + bias_par) * BN));
         bias_par ^= 1;
@@ -1344,6 +1392,17 @@ static int launch_epi(GemmArgs& g, int batch, hipStream_t st) {
     const bool full = g_fast_epi && g.split_k == 1 && !g.out_f32 && !g.trans_out && g.bias_lds &&
                       g.M % BM == 0 && g.N % BN == 0 && (g.ldc & 7) == 0 &&
                       (!g.bias2 || g.rows_per_batch % BM == 0);
+    if (g.ln_stats_out) {
+        // row statistics of the output: only tiles that span the whole row (N == BN), lean epilogue
+        if constexpr ((ALLOW & 256) != 0) {
+            if (full && g.N == BN && g.act == FD_ACT_NONE && g.mode != MODE_CONV && !g.ln_stats && !g.bias2) {
+                if (g.res && (g.ldr & 3) == 0) return launch_mode<BM, BN, false, false, WM, NS, WN, 9>(g, batch, st);
+                if (!g.res) return launch_mode<BM, BN, false, false, WM, NS, WN, 8>(g, batch, st);
+            }
+        }
+        fd_set_error("fd_gemm_f16: ln_stats_out needs N == 320, M %% 256 == 0, a plain or residual linear GEMM");
+        return FD_ESHAPE;
+    }
     if (full && g.ln_stats) {
         if (g.mode != MODE_CONV && !g.res) {
             if constexpr ((ALLOW & 64) != 0 && (BN / WN / 16) % 2 == 0) {
@@ -1519,6 +1578,14 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     if (d->tile) best_tile = d->tile;
     if (d->split_k > 0) best_split = d->split_k;
     if (g.ln_stats) best_split = 1;   // the split-K finish kernel does not know the fold
+    if (d->ln_stats_out) {            // the 256x320 tile spans the whole row: it can finalise the statistics
+        FD_CHECK_ARG(g.N == 320 && g.M % 256 == 0 && !d->conv && !d->trans_out && !d->out_f32, FD_ESHAPE,
+                     "fd_gemm_f16: ln_stats_out needs N == 320 and M %% 256 == 0 (got M=%d N=%d)", g.M, g.N);
+        g.ln_stats_out = d->ln_stats_out;
+        g.ln_eps = d->ln_eps > 0.f ? d->ln_eps : 1e-5f;
+        best_tile = 16;
+        best_split = 1;
+    }
     {
         // The many-wave tiles exist only on the LDS-DMA path, whose buffer descriptors address a
         // tensor through 32-bit byte offsets (< 2 GiB).  Larger operands go to the register-staged
@@ -1566,7 +1633,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         case 14: rc = launch_epi<256, 128, 8, 2, 2, 110>(g, batch, st); break;   // 16 waves, 32x64 wave tiles
         case 8: rc = launch<256, 128, false, 4, 3>(g, batch, st); break;
         case 15: rc = launch_epi<256, 256, 4, 2, 4, 110>(g, batch, st); break;  // 16 waves, 64x64 wave tiles
-        case 16: rc = launch_epi<256, 320, 4, 2, 4, 38>(g, batch, st); break;  // 16 waves, 64x80 wave tiles
+        case 16: rc = launch_epi<256, 320, 4, 2, 4, 294>(g, batch, st); break;  // 16 waves, 64x80 wave tiles
         case 20: rc = launch_epi<128, 160, 4, 3, 2, 38>(g, batch, st); break;   // tile 9 with 3 LDS stages
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }

@@ -31,7 +31,8 @@ class fd_gemm_desc(ctypes.Structure):
                 ('batch_stride_a', c_int64), ('batch_stride_w', c_int64),
                 ('batch_stride_c', c_int64), ('batch_stride_res', c_int64),
                 ('tile', c_int32), ('split_k', c_int32), ('workspace', c_void_p),
-                ('workspace_bytes', c_int64), ('ln_stats', c_void_p), ('ln_colsum', c_void_p)]
+                ('workspace_bytes', c_int64), ('ln_stats', c_void_p), ('ln_colsum', c_void_p),
+                ('ln_stats_out', c_void_p), ('ln_eps', c_float)]
 
 
 class fd_attention_desc(ctypes.Structure):
@@ -124,6 +125,12 @@ def prep_linear_ln(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tens
     return lw
 
 
+def can_emit_row_stats(M: int, N: int) -> bool:
+    '''True when fd_gemm_f16 can write the LayerNorm statistics of its output rows itself
+    (fd_gemm_desc.ln_stats_out: one 256x320 tile spans the whole row).'''
+    return N == 320 and M % 256 == 0
+
+
 def ln_row_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     '''fp16 [rows][C] -> fp32 [rows][2] = (rstd, -mean * rstd) per row (one read of x).'''
     rows, C = x.shape
@@ -196,7 +203,8 @@ def _sched(d: 'fd_gemm_desc', dev: torch.device):
 def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
          bias2: Optional[torch.Tensor] = None, ld_bias2: int = 0, rows_per_sample: int = 0,
          out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0,
-         use_bias: bool = True, ln_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+         use_bias: bool = True, ln_stats: Optional[torch.Tensor] = None,
+         ln_stats_out: Optional[torch.Tensor] = None, ln_eps: float = 1e-5) -> torch.Tensor:
     '''a [M][K] fp16 @ w[N][K]^T with fused epilogue -> [M][N] (GEGLU: [M][N/2]).'''
     M, K = a.shape
     assert a.dtype == torch.float16 and a.stride(1) == 1 and K == w.K, (a.shape, w.K)
@@ -218,6 +226,9 @@ def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[to
     if ln_stats is not None:      # `a` holds the un-normalised rows, `w` comes from prep_linear_ln
         assert w.colsum is not None and ln_stats.shape == (M, 2)
         d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), w.colsum.data_ptr()
+    if ln_stats_out is not None:  # the GEMM also writes the LayerNorm statistics of its output rows
+        assert ln_stats_out.shape == (M, 2) and ln_stats_out.dtype == torch.float32
+        d.ln_stats_out, d.ln_eps = ln_stats_out.data_ptr(), ln_eps
     _sched(d, a.device)
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     return out

@@ -62,6 +62,7 @@ class _Attn:
         # (rstd, mean) per row in their epilogues (fd_gemm_desc.ln_stats; one statistics pass per LayerNorm).
         # FD_UNET_LN_FOLD=0 keeps the separate LayerNorm kernels (A/B).
         self.ln_fold = os.environ.get('FD_UNET_LN_FOLD', '1') != '0'
+        self.ln_emit = os.environ.get('FD_UNET_LN_EMIT', '1') != '0'   # 0: separate statistics pass everywhere (A/B)
         wqk = torch.cat([wq.float() * qs, g(f'{tb}.attn1.to_k.weight').float()], 0)
         wq2 = g(f'{tb}.attn2.to_q.weight').float() * qs
         if self.ln_fold:
@@ -243,9 +244,15 @@ class UNet2DConditionModel():
         B, HW, C = x.B, x.HW, a.C
         d = C // a.heads
         h = ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False)
-        h = ops.gemm(h.t, a.proj_in)
+        # LayerNorm fold: the GEMM that PRODUCES a LayerNorm input also writes its row statistics where one
+        # tile spans the row (C == 320: the 64x64 level); elsewhere one read-only statistics pass
+        emit = a.ln_fold and a.ln_emit and ops.can_emit_row_stats(B * HW, C)
+        mkst = lambda rows: torch.empty((rows, 2), dtype=torch.float32, device=x.t.device) if emit else None
+        st = mkst(B * HW)
+        h = ops.gemm(h.t, a.proj_in, ln_stats_out=st)
         if a.ln_fold:
-            st = ops.ln_row_stats(h)
+            if st is None:
+                st = ops.ln_row_stats(h)
             qk = ops.gemm(h, a.qk1, ln_stats=st)
             vt = ops.gemm_vt(h, a.v1, B, HW, (HW + 7) // 8 * 8, ln_stats=st)
         else:
@@ -254,9 +261,10 @@ class UNet2DConditionModel():
             vt = ops.gemm_vt(n, a.v1, B, HW, (HW + 7) // 8 * 8)
         q, k = qk[:, :C], qk[:, C:]
         o = ops.attention(q, k, vt, B, a.heads, HW, HW, d, q_prescaled=a.q_pre)
-        h = ops.gemm(o, a.o1, residual=h)
+        st = mkst(B * HW)
+        h = ops.gemm(o, a.o1, residual=h, ln_stats_out=st)
         if a.ln_fold:
-            q2 = ops.gemm(h, a.q2, ln_stats=ops.ln_row_stats(h))
+            q2 = ops.gemm(h, a.q2, ln_stats=st if st is not None else ops.ln_row_stats(h))
         else:
             q2 = ops.gemm(ops.layernorm(h, *a.ln[1]), a.q2)
         kc, vtc, L = a.ctx_kv
@@ -269,9 +277,10 @@ class UNet2DConditionModel():
                 ops.attention(q2, kc[r * B * L:(r + 1) * B * L], vtc[r * B:(r + 1) * B], B, a.heads,
                               HW, L, d, q_prescaled=a.q_pre, out=o[r * B * HW:(r + 1) * B * HW])
             h, xt, B = h.repeat(rep, 1), xt.repeat(rep, 1), rep * B
-        h = ops.gemm(o, a.o2, residual=h)
+        st = mkst(B * HW)
+        h = ops.gemm(o, a.o2, residual=h, ln_stats_out=st)
         if a.ln_fold:
-            f = ops.gemm(h, a.ff1, act=ops.ACT_GEGLU, ln_stats=ops.ln_row_stats(h))
+            f = ops.gemm(h, a.ff1, act=ops.ACT_GEGLU, ln_stats=st if st is not None else ops.ln_row_stats(h))
         else:
             f = ops.gemm(ops.layernorm(h, *a.ln[2]), a.ff1, act=ops.ACT_GEGLU)
         h = ops.gemm(f, a.ff2, residual=h)

@@ -32,7 +32,7 @@ extern "C" {
 #define FD_ESHAPE (-2) /* unsupported shape / alignment */
 #define FD_EHIP (-3)   /* HIP runtime error */
 
-#define FD_ABI_VERSION 4
+#define FD_ABI_VERSION 5
 
 int fd_abi_version(void);
 const char* fd_last_error(void);
@@ -162,6 +162,12 @@ typedef struct fd_gemm_desc {
      * Linear GEMMs only; act NONE or GEGLU; works with trans_out.  NULL = off. */
     const float* ln_stats;  /* fp32 [M][2] */
     const float* ln_colsum; /* fp32 [N] */
+    /* Producer side of the fold: also write ln_stats_out[m] = (rstd_m, -mean_m rstd_m) of the OUTPUT rows
+     * (LayerNorm over the N columns, eps ln_eps, statistics of the fp16-rounded values), so that the next
+     * GEMM can take them as its ln_stats without a separate statistics pass.  Only where one workgroup
+     * tile spans the whole row: N == 320, M % 256 == 0, linear, plain or residual epilogue. NULL = off. */
+    float* ln_stats_out;
+    float ln_eps;
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);

@@ -360,3 +360,30 @@ def test_gemm_layernorm_fold_geglu_and_transposed(dev, M, C):
         vt = ops.gemm_vt(xd, lv, B, HW, HW, ln_stats=st).float().cpu()
         want_v = _ln_ref(x, gamma, beta, wv, None).view(B, HW, C).permute(0, 2, 1)
         assert float((vt - want_v).abs().max()) < 2e-2 * float(want_v.abs().max())
+
+
+@pytest.mark.parametrize('M,res', [(65536, True), (2048, False), (256, True)])
+def test_gemm_emits_row_stats_of_its_output(dev, M, res):
+    '''fd_gemm_desc.ln_stats_out: the 256x320 tile spans the whole row (N = 320) and writes
+    (rstd, -mean rstd) of the fp16 rows it stores -- the LayerNorm statistics its consumer GEMM folds
+    in -- identical in meaning to fd_ln_row_stats_f16 on the stored output.'''
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(M)
+    N = K = 320
+    a = torch.randn((M, K), generator=g).half().to(dev)
+    w = ops.prep_linear(torch.randn((N, K), generator=g) * K ** -0.5, torch.randn(N, generator=g) * 0.5, dev)
+    r = (torch.randn((M, N), generator=g) * 2 + torch.randn((M, 1), generator=g) * 3).half().to(dev) if res else None
+    st = torch.empty((M, 2), dtype=torch.float32, device=dev)
+    out = ops.gemm(a, w, residual=r, ln_stats_out=st)
+    plain = ops.gemm(a, w, residual=r)
+    # same values as the launch without statistics (which may pick another tile: last-bit differences only)
+    assert float((out.float() - plain.float()).abs().max()) <= 2e-3 * float(plain.float().abs().max())
+    ref = ops.ln_row_stats(out)                          # exact two-pass statistics of the stored rows
+    x = out.float()
+    assert torch.allclose(ref[:, 0], (x.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
+    # one-pass E[x^2] - mean^2 in fp32 vs the exact two-pass: relative 1e-4 on rstd, absolute 1e-4 on -mean rstd
+    assert float(((st[:, 0] - ref[:, 0]).abs() / ref[:, 0]).max()) < 2e-4
+    assert float((st[:, 1] - ref[:, 1]).abs().max()) < 2e-4 * max(1.0, float(ref[:, 1].abs().max()))
+    assert not ops.can_emit_row_stats(M, 640)
+    with pytest.raises(ValueError):
+        ops.gemm(a[:, :K], ops.prep_linear(torch.zeros((640, K)), None, dev), ln_stats_out=st)
