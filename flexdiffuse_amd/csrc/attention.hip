@@ -581,6 +581,290 @@ __global__ __launch_bounds__(512, (DV <= 3 ? ATT_W8_MINW : DQK <= 96 ? 2 : 1)) v
 #endif
 }
 
+// ---------------------------------------------------------------------------------------
+// Two 16-query blocks per wave (256 queries per workgroup).  On this chip the instructions of
+// a SIMD's waves ADD UP (tools/micro/pipe_overlap.hip: no overlap between v_mfma_f32_16x16x32
+// and VALU / DS issue), so the tile loop is bound by its instruction count per score.  Both
+// query blocks share every K and V^T fragment read and the K / V^T tile staging: DS
+// instructions and global loads per score halve; MFMA, exp and convert counts per score are
+// unchanged.  ~125 VGPRs (4 waves per SIMD: the kernel is not sensitive to occupancy,
+// tools/ab_attn_occ.py).  Same arithmetic per query as k_attention_w8.
+template <int DQK, int DV, bool PRE, bool ONES>
+__global__ __launch_bounds__(512, 2) void k_attention_w8q2(AttnArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KS = DQK / 32;
+    constexpr int NT = 512;
+    constexpr int KCH = DQK / 8;
+    constexpr int KSTR = (KCH + 2) * 16;
+    constexpr int VSTR = 10 * 16;
+    constexpr int VROWS = DV * 16;
+    constexpr int KLD = (64 * KCH + NT - 1) / NT;
+    constexpr int VLD = (VROWS * 8 + NT - 1) / NT;
+    constexpr int KBYTES = 64 * KSTR, VBYTES = VROWS * VSTR;
+    constexpr unsigned OOB = 0x7fffffffu;
+    __shared__ __attribute__((aligned(16))) char sKV[2 * (KBYTES + VBYTES)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int nqb = (a.Nq + 255) >> 8;
+    const int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, slot = id >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int qb = id % nqb, h = (id / nqb) % a.heads, b = id / (nqb * a.heads);
+    const int qblk0 = qb * 256;
+    const int q0 = qblk0 + wave * 32;   // this wave's queries: q0 .. q0+31 (two fragments of 16)
+    const int d = a.d;
+    const half_t* __restrict__ Qb = a.Q + (size_t)b * a.sQ + h * d;
+    const half_t* Kb = a.K + (size_t)b * a.sK + h * d;
+    const half_t* Vb = a.Vt + (size_t)b * a.sVt + (size_t)h * d * a.ldvt;
+    half_t* __restrict__ Ob = a.O + (size_t)b * a.sO + h * d;
+    const int nk8 = (a.Nk + 7) & ~7;
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Kb, 0, (unsigned)(((size_t)(a.Nk - 1) * a.ldk + d) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Vb, 0, (unsigned)(((size_t)(d - 1) * a.ldvt + nk8) * 2), 0x00020000);
+
+    half8 qf[2][KS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int q = q0 + t * 16 + fr, d0 = (ks * 4 + g) * 8;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (q < a.Nq && d0 < d) v = *reinterpret_cast<const u32x4*>(Qb + (size_t)q * a.ldq + d0);
+            qf[t][ks] = __builtin_bit_cast(half8, v);
+        }
+
+    floatx4 o[2][DV];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int dt = 0; dt < DV; ++dt) o[t][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float m_used[2] = {0.f, 0.f};  // running (lazy) max per query block, in base-2 logit units
+    floatx4 init[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // PRE: -m_used, the QK^T accumulator input
+    float lrow[2] = {0.f, 0.f};
+
+    int ntiles = (a.Nk + 63) >> 6;
+    if (a.causal) {
+        const int qend = min(a.Nq, qblk0 + 256);
+        ntiles = min(ntiles, (qend + 63) >> 6);
+    }
+
+    // per-thread constant load offsets / LDS store addresses
+    unsigned kvo[KLD], vvo[VLD];
+    // LDS store offsets of this thread's K chunk (low 16 bits) and V^T chunk (high 16 bits) in ONE
+    // register: at the 64-VGPR budget of 8 waves/SIMD the separate V offset was spilled to scratch
+    // and reloaded (scratch_load + vmcnt(0)) in every K/V tile iteration
+    unsigned kvst[KLD > VLD ? KLD : VLD];
+    static_assert(2 * (KBYTES + VBYTES) < 65536 + 65536, "LDS offsets must fit 16 bits");
+    bool vones[VLD], vlive[VLD];
+#pragma unroll
+    for (int i = 0; i < KLD; ++i) {
+        const int e = tid + NT * i;
+        const int row = e / KCH, c = e - row * KCH;
+        kvo[i] = (e < 64 * KCH && c * 8 < d) ? (unsigned)(row * a.ldk + c * 8) * 2u : OOB;
+        kvst[i] = (unsigned)(row * KSTR + c * 16);
+    }
+#pragma unroll
+    for (int i = KLD; i < VLD; ++i) kvst[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+        const int e = tid + NT * i;
+        const int row = e >> 3, c = e & 7;
+        vvo[i] = (e < VROWS * 8 && row < d) ? (unsigned)(row * a.ldvt + c * 8) * 2u : OOB;
+        vones[i] = ONES && row == d;
+        vlive[i] = e < VROWS * 8 && row < d;
+        const int grp = c >> 2, cc = c & 3;
+        const int pos = grp * 32 + (cc & 1) * 16 + (cc >> 1) * 4;  // halfs (see k_attention)
+        kvst[i] |= (unsigned)(KBYTES + row * VSTR + pos * 2) << 16;
+        asm volatile("" : "+v"(kvst[i]));   // opaque: keeps the optimizer from un-packing the two halves again
+    }
+
+    u32x4 rk[KLD], rv[VLD];
+#define ATT_LOAD(J)                                                                           \
+    {                                                                                         \
+        const int key0 = (J) * 64;                                                            \
+        if (key0 + 64 <= a.Nk) { /* full tile: constant per-lane offsets + scalar tile offset */ \
+            _Pragma("unroll") for (int i = 0; i < KLD; ++i)                                   \
+                rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, kvo[i], key0 * a.ldk * 2, 0); \
+            _Pragma("unroll") for (int i = 0; i < VLD; ++i)                                   \
+                rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, vvo[i], key0 * 2, 0);      \
+        } else { /* ragged last tile: rows / key chunks past the end read zero */             \
+            _Pragma("unroll") for (int i = 0; i < KLD; ++i) {                                 \
+                const unsigned vo = (key0 + (tid + NT * i) / KCH < a.Nk) ? kvo[i] + (unsigned)key0 * a.ldk * 2u : OOB; /* row recomputed: rare path */ \
+                rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, vo, 0, 0);                 \
+            }                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < VLD; ++i) {                                 \
+                const unsigned vo = (key0 + ((tid + NT * i) & 7) * 8 < nk8) ? vvo[i] + (unsigned)key0 * 2u : OOB; \
+                rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, vo, 0, 0);                 \
+            }                                                                                 \
+        }                                                                                     \
+    }
+#define ATT_STORE(BUF)                                                                        \
+    {                                                                                         \
+        char* sb = sKV + (BUF) * (KBYTES + VBYTES);                                           \
+        _Pragma("unroll") for (int i = 0; i < KLD; ++i)                                       \
+            if (KLD * NT == 64 * KCH || tid + NT * i < 64 * KCH)                              \
+                *reinterpret_cast<u32x4*>(sb + (kvst[i] & 0xffffu)) = rk[i];                               \
+        _Pragma("unroll") for (int i = 0; i < VLD; ++i)                                       \
+            if (vlive[i]) {                                                                   \
+                *reinterpret_cast<u32x2*>(sb + (kvst[i] >> 16)) = u32x2{rv[i][0], rv[i][1]};  \
+                *reinterpret_cast<u32x2*>(sb + (kvst[i] >> 16) + 16) = u32x2{rv[i][2], rv[i][3]}; \
+            }                                                                                 \
+    }
+
+    // V^T rows >= head_dim never change: zero padding, and with ONES row `d` = 1.0 so that the
+    // PV MFMA also accumulates the softmax denominator.  Written once, to both stages.
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+        const int e = tid + NT * i;
+        if (e < VROWS * 8 && !vlive[i]) {
+            const unsigned w = vones[i] ? 0x3C003C00u : 0u;
+#pragma unroll
+            for (int buf = 0; buf < 2; ++buf) {
+                char* sb = sKV + buf * (KBYTES + VBYTES);
+                *reinterpret_cast<u32x2*>(sb + (kvst[i] >> 16)) = u32x2{w, w};
+                *reinterpret_cast<u32x2*>(sb + (kvst[i] >> 16) + 16) = u32x2{w, w};
+            }
+        }
+    }
+    ATT_LOAD(0);
+    ATT_STORE(0);
+    __syncthreads();
+    const float c2 = a.scale_log2;
+    const floatx2 c2v = {c2, c2};
+
+    for (int j = 0; j < ntiles; ++j) {
+        if (j + 1 < ntiles) ATT_LOAD(j + 1);
+        const char* sK = sKV + (j & 1) * (KBYTES + VBYTES);
+        const char* sV = sK + KBYTES;
+        const bool need_mask = (j * 64 + 64 > a.Nk) || a.causal;
+        floatx4 s[2][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 kf = *reinterpret_cast<const half8*>(sK + (f * 16 + fr) * KSTR +
+                                                                 (ks * 4 + g) * 16);
+                s[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], ks == 0 ? init[0] : s[0][f], 0, 0, 0);
+                s[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], ks == 0 ? init[1] : s[1][f], 0, 0, 0);
+            }
+        half8 p[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (!PRE) {
+                const floatx2 mv = {m_used[t], m_used[t]};
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        floatx2 x = {s[t][f][r], s[t][f][r + 1]};
+                        x = x * c2v - mv;
+                        s[t][f][r] = x[0];
+                        s[t][f][r + 1] = x[1];
+                    }
+            }
+            if (need_mask) {
+                const int q = q0 + t * 16 + fr;
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = j * 64 + f * 16 + g * 4 + r;
+                        if (key >= a.Nk || (a.causal && key > q)) s[t][f][r] = -INFINITY;
+                    }
+            }
+            float tmax;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(s[t][0][0]), "v"(s[t][0][1]), "v"(s[t][0][2]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[t][0][3]), "v"(s[t][1][0]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[t][1][1]), "v"(s[t][1][2]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[t][1][3]), "v"(s[t][2][0]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[t][2][1]), "v"(s[t][2][2]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[t][2][3]), "v"(s[t][3][0]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[t][3][1]), "v"(s[t][3][2]));
+            asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(tmax), "v"(s[t][3][3]));
+            if (j == 0 || __any(tmax > LAZY_THR)) {
+                // advance the running max to the exact row max (rare after the first tiles)
+                const float tm = xor_max_16_32(tmax);
+                float delta = (j == 0) ? tm : fmaxf(tm, 0.f);
+                if (delta == -INFINITY) delta = 0.f;
+                const float alpha = (j == 0) ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                m_used[t] += delta;
+                if (PRE) init[t] = floatx4{-m_used[t], -m_used[t], -m_used[t], -m_used[t]};
+                lrow[t] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DV; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[t][dt][r] *= alpha;
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[t][f][r] -= delta;
+            }
+            floatx2 ps = {0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const floatx2 e = {__builtin_amdgcn_exp2f(s[t][f][r]), __builtin_amdgcn_exp2f(s[t][f][r + 1])};
+                    if (!ONES) ps += e;
+                    const half2v eh = __builtin_convertvector(e, half2v);
+                    p[t][f >> 1][(f & 1) * 4 + r] = eh[0];
+                    p[t][f >> 1][(f & 1) * 4 + r + 1] = eh[1];
+                }
+            if (!ONES) lrow[t] += ps[0] + ps[1];
+        }
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+            for (int dt = 0; dt < DV; ++dt) {
+                const half8 vf = *reinterpret_cast<const half8*>(sV + (dt * 16 + fr) * VSTR +
+                                                                 (kg * 4 + g) * 16);
+                o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, p[0][kg], o[0][dt], 0, 0, 0);
+                o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, p[1][kg], o[1][dt], 0, 0, 0);
+            }
+        if (j + 1 < ntiles) ATT_STORE((j + 1) & 1);
+        __syncthreads();
+    }
+#undef ATT_LOAD
+#undef ATT_STORE
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float l;
+        if (ONES) {
+            // denominator = O^T row d: lane group g = (d>>2)&3, fragment d>>4, element 0
+            float lv = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DV; ++dt)
+                if (dt == (d >> 4)) lv = o[t][dt][0];
+            l = __shfl(lv, ((d >> 2) & 3) * 16 + fr, 64);
+        } else {
+            l = lrow[t];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
+        const float inv = 1.0f / l;
+        const int q = q0 + t * 16 + fr;
+        if (q < a.Nq) {
+#pragma unroll
+            for (int dt = 0; dt < DV; ++dt) {
+                const int d0 = dt * 16 + g * 4;
+                if (d0 >= d) continue;
+                half4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[t][dt][r] * inv);
+                *reinterpret_cast<half4*>(Ob + (size_t)q * a.ldo + d0) = v;
+            }
+        }
+    }
+#endif
+}
+
+
 extern "C" int fd_attention_f16(const fd_attention_desc* d, void* stream) {
     FD_CHECK_ARG(d && d->Q && d->K && d->Vt && d->O, FD_EINVAL, "fd_attention_f16: null pointer");
     FD_CHECK_ARG(d->batch > 0 && d->heads > 0 && d->n_q > 0 && d->n_k > 0, FD_EINVAL,
@@ -612,6 +896,8 @@ extern "C" int fd_attention_f16(const fd_attention_desc* d, void* stream) {
     // 2 (default) = 8-wave kernel with the VALU-lean softmax (lazy max, fused denominator)
     static const int wide = getenv("FD_ATTN_QT1") ? atoi(getenv("FD_ATTN_QT1")) : 2;
     const bool pre = d->q_prescaled != 0;
+    // two query blocks per wave for the long self-attention rows (FD_ATTN_Q2=0: one block, A/B)
+    static const int q2 = getenv("FD_ATTN_Q2") ? atoi(getenv("FD_ATTN_Q2")) : 1;
     FD_CHECK_ARG(!pre || (wide == 2 && (hd <= 80 || hd > 128)), FD_ESHAPE,
                  "fd_attention_f16: q_prescaled is not supported for head_dim=%d", hd);
 #define ATT_W8(DQK, DV, ONES)                                                                  \
@@ -619,7 +905,16 @@ extern "C" int fd_attention_f16(const fd_attention_desc* d, void* stream) {
         if (pre) hipLaunchKernelGGL((k_attention_w8<DQK, DV, true, ONES>), grid, dim3(512), 0, st, a); \
         else hipLaunchKernelGGL((k_attention_w8<DQK, DV, false, ONES>), grid, dim3(512), 0, st, a);    \
     }
-    if (hd <= 48) {
+    if (hd <= 48 && wide == 2 && q2 && d->n_q >= 2048 && d->n_k >= 1024) {
+        dim3 grid2(fd_cdiv(d->n_q, 256) * d->heads * d->batch);
+        if (hd <= 40) {
+            if (pre) hipLaunchKernelGGL((k_attention_w8q2<64, 3, true, true>), grid2, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((k_attention_w8q2<64, 3, false, true>), grid2, dim3(512), 0, st, a);
+        } else {
+            if (pre) hipLaunchKernelGGL((k_attention_w8q2<64, 3, true, false>), grid2, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((k_attention_w8q2<64, 3, false, false>), grid2, dim3(512), 0, st, a);
+        }
+    } else if (hd <= 48) {
         if (wide == 2 && hd <= 40) ATT_W8(64, 3, true)
         else if (wide == 2) ATT_W8(64, 3, false)
         else if (wide) hipLaunchKernelGGL((k_attention<64, 3, 1, 8>), grid, dim3(512), 0, st, a);

@@ -154,7 +154,9 @@ def attn_ref(q, k, v, heads, causal=False):
 @pytest.mark.parametrize('Nq,Nk,heads,d,causal', [(256, 256, 8, 40, False), (1024, 1024, 2, 40, False),
                                                   (256, 77, 8, 40, False), (64, 64, 8, 160, False),
                                                   (256, 256, 8, 80, False), (100, 77, 8, 160, False),
-                                                  (77, 77, 12, 64, True), (257, 257, 4, 64, False)])
+                                                  (77, 77, 12, 64, True), (257, 257, 4, 64, False),
+                                                  (2048, 1024, 2, 40, False), (2200, 1100, 1, 48, False),
+                                                  (2048, 2048, 1, 40, True)])
 def test_attention(dev, Nq, Nk, heads, d, causal):
     from flexdiffuse_amd import ops
     B, C = 2, heads * d
@@ -174,7 +176,10 @@ def test_attention(dev, Nq, Nk, heads, d, causal):
                                                   (256, 77, 8, 40, False), (64, 64, 8, 160, False),
                                                   (256, 250, 8, 80, False), (100, 77, 8, 160, False),
                                                   (77, 77, 12, 64, True), (130, 200, 2, 48, False),
-                                                  (192, 320, 2, 32, False)])
+                                                  (192, 320, 2, 32, False),
+                                                  # >= 2048 queries x >= 1024 keys: two query blocks per wave
+                                                  (2048, 1024, 2, 40, False), (4096, 4096, 1, 40, False),
+                                                  (2100, 1030, 2, 48, False), (2048, 1024, 1, 32, True)])
 def test_attention_prescaled_q(dev, Nq, Nk, heads, d, causal):
     '''q_prescaled: Q carries head_dim^-0.5 * log2(e); the kernel feeds the running max into
     the QK^T MFMA accumulator and (head_dim <= 40) takes the denominator from the PV MFMA.
