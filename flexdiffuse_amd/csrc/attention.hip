@@ -293,6 +293,9 @@ __global__ __launch_bounds__(64 * NW, (DQK <= 96 ? 2 : 1)) void k_attention(Attn
 #ifndef ATT_VPRE
 #define ATT_VPRE 0
 #endif
+#ifndef ATT_SETPRIO
+#define ATT_SETPRIO 0   // s_setprio(1) around the MFMA clusters of k_attention_w8q2 (measured: see profiles)
+#endif
 #ifndef ATT_W8_MINW
 #define ATT_W8_MINW 8   // waves per SIMD the d <= 48 kernel is compiled for (8: 64 VGPRs, 6: 80 VGPRs)
 #endif
@@ -743,6 +746,9 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8q2(AttnArgs a) {
         const char* sV = sK + KBYTES;
         const bool need_mask = (j * 64 + 64 > a.Nk) || a.causal;
         floatx4 s[2][4];
+#if ATT_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -752,6 +758,9 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8q2(AttnArgs a) {
                 s[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], ks == 0 ? init[0] : s[0][f], 0, 0, 0);
                 s[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], ks == 0 ? init[1] : s[1][f], 0, 0, 0);
             }
+#if ATT_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         half8 p[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -817,6 +826,9 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8q2(AttnArgs a) {
                 }
             if (!ONES) lrow[t] += ps[0] + ps[1];
         }
+#if ATT_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
@@ -826,6 +838,9 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8q2(AttnArgs a) {
                 o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, p[0][kg], o[0][dt], 0, 0, 0);
                 o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, p[1][kg], o[1][dt], 0, 0, 0);
             }
+#if ATT_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (j + 1 < ntiles) ATT_STORE((j + 1) & 1);
         __syncthreads();
     }

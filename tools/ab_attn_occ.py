@@ -4,7 +4,7 @@ import sys, os, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if len(sys.argv) == 1:
-    libs = [('q2', None), ('q1', 'ENV:FD_ATTN_Q2=0')] + 0* [(os.path.basename(f)[4:-3], 'tools/_variants/' + os.path.basename(f))
+    libs = [('q2', None)] + [(os.path.basename(f)[4:-3], 'tools/_variants/' + os.path.basename(f))
                              for f in sorted(__import__('glob').glob(os.path.join(ROOT, 'tools/_variants/lib_att*.so')))]
     for name, lib in libs * 2:
         env = dict(os.environ)
