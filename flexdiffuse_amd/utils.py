@@ -25,20 +25,36 @@ from .guidance import Guide
 from .composition import CompositeGuide, EntitySchema, Schema
 from .pipeline.guide import GuideBase, SimpleGuide
 
-MAX_SEED = 2147483647
+MAX_SEED = 2147483647          # the reference clamps seeds to int32 (utils.py:22)
+
+# the keyword arguments `gen` forwards untouched to `Guide.embeds` (utils.py:151-162)
+_EMBEDS_KEYS = ('mapping_concepts', 'guide_threshold_mult', 'guide_threshold_floor', 'guide_clustered',
+                'guide_linear', 'guide_max_guidance', 'guide_header_max', 'guide_mode', 'guide_reuse')
 
 
 def image_grid(imgs: Sequence[Any]):
-    '''Grid arrangement of PIL images: ceil(sqrt(n)) columns, n // cols rows (utils.py:36-50).'''
+    '''Paste PIL images into one sheet, row-major: ceil(sqrt(n)) columns and n // columns rows, so
+    the last images are dropped when they do not fill a row (the reference's arithmetic,
+    utils.py:36-50).'''
     from PIL import Image
-    num = len(imgs)
-    cols = math.ceil(num ** (1 / 2))
-    rows = num // cols
+    cols = math.ceil(math.sqrt(len(imgs)))
+    rows = len(imgs) // cols
     w, h = imgs[0].size
-    grid = Image.new('RGB', size=(cols * w, rows * h))
-    for i, img in enumerate(imgs):
-        grid.paste(img, box=((i % cols) * w, (i // cols) * h))
-    return grid
+    sheet = Image.new('RGB', size=(cols * w, rows * h))
+    for k, img in enumerate(imgs):
+        sheet.paste(img, box=(k % cols * w, k // cols * h))
+    return sheet
+
+
+def entity_from_row(row: Sequence[Any]) -> Optional[EntitySchema]:
+    '''One table row [prompt, x, y, width, height, blend] -> EntitySchema, or None when it cannot be
+    coerced (the reference reports and skips such rows, utils.py:188-196).'''
+    try:
+        prompt, x, y, w, h, blend = (row[k] for k in range(6))
+        return EntitySchema(str(prompt).strip(), (int(x), int(y)), (int(w), int(h)), float(blend))
+    except Exception as ex:          # noqa: BLE001 -- the reference catches everything here
+        print('Failed to build EntitySchema:', ex)
+        return None
 
 
 class Runner():
@@ -47,30 +63,28 @@ class Runner():
         if state_dicts is None:
             state_dicts = build.synthetic_state_dicts(preset, seed=seed_weights)
         self.pipe, clip, tok = build.build_models(state_dicts, preset, device)
-        self.eta = 0.0
+        self.device = device
         self.encoder = CLIPEncoder(clip, tok)
         self.guide = Guide(clip, tok, device=device)
-        self.device = device
-        self.generator = torch.Generator(device='cpu')
+        self.generator = torch.Generator(device='cpu')     # E6: host generator
+        self.eta = 0.0                                      # E5: never overwritten
 
     def _set_seed(self, seed: Optional[int]):
-        '''utils.py:78-83: falsy seed -> random; else clamped to [0, 2^31-1].'''
-        if not seed:
-            seed = int(torch.randint(0, MAX_SEED, (1,))[0])
-        else:
-            seed = min(max(seed, 0), MAX_SEED)
+        '''Falsy seed -> a random one; otherwise clamped to [0, 2^31 - 1] (utils.py:78-83).'''
+        seed = min(max(seed, 0), MAX_SEED) if seed else int(torch.randint(0, MAX_SEED, (1,))[0])
         self.generator.manual_seed(seed)
         return seed
 
     def _run(self, batches: int, guide: GuideBase, init_image, init_size: Tuple[int, int],
              strength: float, debug: bool):
-        all_images: List[Any] = []
-        for _ in range(batches):      # the reference's only data-parallel axis (utils.py:90)
-            output = self.pipe(guide=guide, init_image=init_image, init_size=init_size,
-                               strength=strength, generator=self.generator, eta=self.eta,
-                               debug=debug)
-            all_images.extend(output['sample'])
-        return all_images, image_grid(all_images)
+        '''`batches` sequential pipeline calls on one generator stream -- the reference's only
+        data-parallel axis (utils.py:90) -- and the grid of everything they produced.'''
+        images: List[Any] = []
+        for _ in range(batches):
+            result = self.pipe(guide=guide, init_image=init_image, init_size=init_size, strength=strength,
+                               generator=self.generator, eta=self.eta, debug=debug)
+            images += list(result['sample'])
+        return images, image_grid(images)
 
     def gen(self,
             prompt='',
@@ -93,16 +107,11 @@ class Runner():
             seed: Optional[int] = None,
             debug: bool = False):
         '''Same arguments and defaults as utils.py:114-133; returns (images, grid).'''
+        given = locals()
         self._set_seed(seed)
-        guide_embeds = self.guide.embeds(
-            prompt=prompt, guide=guide, mapping_concepts=mapping_concepts,
-            guide_threshold_mult=guide_threshold_mult, guide_threshold_floor=guide_threshold_floor,
-            guide_clustered=guide_clustered, guide_linear=guide_linear,
-            guide_max_guidance=guide_max_guidance, guide_header_max=guide_header_max,
-            guide_mode=guide_mode, guide_reuse=guide_reuse)
-        pipeline_guide = SimpleGuide(self.encoder, self.pipe.unet, guidance_scale, steps,
-                                     guide_embeds)
-        return self._run(samples, pipeline_guide, init_image, init_size, strength, debug)
+        embeds = self.guide.embeds(prompt=prompt, guide=guide, **{k: given[k] for k in _EMBEDS_KEYS})
+        return self._run(samples, SimpleGuide(self.encoder, self.pipe.unet, guidance_scale, steps, embeds),
+                         init_image, init_size, strength, debug)
 
     def compose(self,
                 bg_prompt: str = '',
@@ -118,25 +127,12 @@ class Runner():
                 init_size: Tuple[int, int] = (512, 512),
                 seed: Optional[int] = None,
                 debug: bool = False):
-        '''Same arguments and defaults as utils.py:168-181; returns (images, grid).  Each row of
-        `entities_df` is [prompt, offset_x, offset_y, width, height, blend] (a DataFrame is
-        accepted through its `_values`, utils.py:198-199); a row that does not parse is reported
-        and skipped, rows with an empty prompt are dropped (utils.py:188-201).'''
+        '''Same arguments and defaults as utils.py:168-181; returns (images, grid).  `entities_df`
+        rows are [prompt, offset_x, offset_y, width, height, blend]; a DataFrame is taken through
+        its `_values` (utils.py:198-199); rows that do not parse or have an empty prompt are dropped.'''
         self._set_seed(seed)
-
-        def _row_to_ent(row) -> Optional[EntitySchema]:
-            try:
-                return EntitySchema(str(row[0]).strip(), (int(row[1]), int(row[2])),
-                                    (int(row[3]), int(row[4])), float(row[5]))
-            except Exception as ex:
-                print('Failed to build EntitySchema:', ex)
-                return None
-
-        if hasattr(entities_df, '_values'):
-            entities_df = entities_df._values
-        rows = [_row_to_ent(r) for r in entities_df]
-        rows = [r for r in rows if r and r.prompt]
-        schema = Schema(bg_prompt, start_style, end_style, style_blend, rows)
-        self.last_schema = schema
-        pipeline_guide = CompositeGuide(self.encoder, self.pipe.unet, guidance_scale, schema, steps)
-        return self._run(batches, pipeline_guide, init_image, init_size, strength, debug)
+        table = getattr(entities_df, '_values', entities_df)
+        entities = [e for e in map(entity_from_row, table) if e is not None and e.prompt]
+        self.last_schema = Schema(bg_prompt, start_style, end_style, style_blend, entities)
+        guide = CompositeGuide(self.encoder, self.pipe.unet, guidance_scale, self.last_schema, steps)
+        return self._run(batches, guide, init_image, init_size, strength, debug)
