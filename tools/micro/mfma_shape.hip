@@ -14,6 +14,7 @@ typedef _Float16 half_t;
 typedef half_t half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BM = 256, BN = 256, STAGE = (BM + BN) * 128;
 
 template <int SHAPE, int MODE>
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(1024) void k(float* out, int nk, int rnd) {
     __syncthreads();
     float s = 0;
     int cur = 0;
-    if constexpr (SHAPE == 16) {
+    if constexpr (SHAPE == 16 || SHAPE == 17) {
         const int fr = lane & 15, fq = lane >> 4;
         const int frag_a = (wm * 64 + fr) * 128, frag_b = BM * 128 + (wn * 64 + fr) * 128;
         floatx4 acc[4][4];
@@ -53,7 +54,10 @@ __global__ __launch_bounds__(1024) void k(float* out, int nk, int rnd) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                        if constexpr (SHAPE == 17)   // same bits reinterpreted as bf16: same LDS traffic, bf16 multipliers
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
             }
             if (MODE >= 2) __syncthreads();
             if (MODE >= 1) cur ^= 1;
@@ -115,8 +119,8 @@ int main() {
     float* out; hipMalloc(&out, 256 * 1024 * 4);
     for (int rep = 0; rep < 2; ++rep)
         for (int rnd = 0; rnd < 2; ++rnd) {
-            run<16, 0>(out, rnd); run<32, 0>(out, rnd);
-            run<16, 1>(out, rnd); run<32, 1>(out, rnd);
+            run<16, 0>(out, rnd); run<17, 0>(out, rnd); run<32, 0>(out, rnd);
+            run<16, 1>(out, rnd); run<17, 1>(out, rnd); run<32, 1>(out, rnd);
             run<16, 2>(out, rnd); run<32, 2>(out, rnd);
         }
     return 0;
