@@ -118,11 +118,12 @@ def load_state_dicts(sd_dir: str, clip_dir: str, preset: str = 'sd15') -> Dict[s
 
 
 def load_tokenizer(tokenizer_dir: str):
-    '''The real BPE tokenizer (vocab.json + merges.txt on disk) through transformers; the
-    containers only need `__call__(..., padding, max_length, truncation, return_tensors)` and
-    `model_max_length` (encode/clip.py:57-63).'''
-    from transformers import CLIPTokenizer
-    return CLIPTokenizer.from_pretrained(tokenizer_dir, local_files_only=True)
+    '''The real BPE tokenizer from vocab.json + merges.txt on disk (the tokenizer/ folder of the
+    checkpoint the reference's Runner downloads, utils.py:61-63).  The containers only need
+    `__call__(..., padding, max_length, truncation, return_tensors)` and `model_max_length`
+    (encode/clip.py:57-63).'''
+    from .tokenizer import CLIPBPETokenizer
+    return CLIPBPETokenizer.from_pretrained(tokenizer_dir)
 
 
 def configs(preset: str):

@@ -3,16 +3,23 @@
 truncation=True, return_tensors='pt').input_ids`, `.model_max_length`).
 
 Neither box holds the CLIP BPE vocabulary, so `SyntheticTokenizer` maps
-each word to a stable pseudo-id (crc32) between the real BOS/EOS ids.  A real
-`transformers.CLIPTokenizer` can be passed to every class here instead; only the call
-surface above is relied on.
+each word to a stable pseudo-id (crc32) between the real BOS/EOS ids.  Where the vocabulary
+IS on disk (vocab.json + merges.txt of "openai/clip-vit-large-patch14", what the reference's
+`Runner.__init__` downloads, utils.py:24-25, 61-68), `CLIPBPETokenizer` is the byte-level BPE
+itself: no transformers import on the product path.  It is checked id-for-id against
+`transformers.CLIPTokenizer` on a toy vocabulary in tests/test_tokenizer.py.  A real
+`transformers.CLIPTokenizer` can also be passed to every class here; only the call surface
+above is relied on.
 '''
 from __future__ import annotations
 
+import json
+import os
 import re
+import unicodedata
 import zlib
 from types import SimpleNamespace
-from typing import List, Union
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
 import torch
 
@@ -44,4 +51,127 @@ class SyntheticTokenizer():
             ids = ids + [self.eos_token_id]
             ids = ids + [self.pad_token_id] * (L - len(ids))
             rows.append(ids[:L])
+        return SimpleNamespace(input_ids=torch.tensor(rows, dtype=torch.long))
+
+
+def _byte_alphabet() -> Dict[int, str]:
+    '''The byte -> printable-character table of byte-level BPE (GPT-2 / CLIP): the printable
+    Latin-1 bytes stand for themselves, the other 68 are moved to U+0100 onwards in byte order.'''
+    keep = [b for b in range(256) if 33 <= b <= 126 or 161 <= b <= 172 or 174 <= b <= 255]
+    table, spare = {}, 0
+    for b in range(256):
+        if b in keep:
+            table[b] = chr(b)
+        else:
+            table[b] = chr(256 + spare)
+            spare += 1
+    return table
+
+
+class CLIPBPETokenizer():
+    '''CLIP's lower-cased byte-level BPE with the Hugging Face call surface.
+
+    Text -> NFC, runs of whitespace -> one space, lower case -> pieces (the two special tokens,
+    the English clitics 's 't 're 've 'm 'll 'd, letter runs, SINGLE digits, runs of other
+    non-space characters) -> UTF-8 bytes as printable characters, the last one of each piece
+    carrying "</w>" -> greedy lowest-rank pair merges -> vocabulary ids.  Rows are
+    `[BOS] ids [EOS]`, truncated so that EOS survives, padded with `pad_token` (the EOS token
+    for SD1.x; "!" = id 0 for the SD2.x tokenizer).'''
+
+    BOS, EOS = '<|startoftext|>', '<|endoftext|>'
+
+    def __init__(self, vocab: Dict[str, int], merges: Iterable[Union[str, Sequence[str]]],
+                 model_max_length: int = 77, pad_token: Optional[str] = None):
+        import regex
+        self.vocab = dict(vocab)
+        pairs = []
+        for m in merges:
+            if isinstance(m, str):
+                if not m.strip() or m.startswith('#version'):
+                    continue
+                m = m.split()
+            pairs.append((m[0], m[1]))
+        self.rank: Dict[Tuple[str, str], int] = {p: i for i, p in enumerate(pairs)}
+        self.model_max_length = model_max_length
+        self.vocab_size = len(self.vocab)
+        self.bos_token_id = self.vocab[self.BOS]
+        self.eos_token_id = self.vocab[self.EOS]
+        self.unk_token_id = self.eos_token_id
+        self.pad_token_id = self.vocab[pad_token] if pad_token is not None else self.eos_token_id
+        self._bytes = _byte_alphabet()
+        self._pieces = regex.compile(
+            r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|\p{L}+|\p{N}|[^\s\p{L}\p{N}]+")
+        self._space = regex.compile(r'\s+')
+        self._memo: Dict[str, List[str]] = {}
+
+    @classmethod
+    def from_pretrained(cls, directory: str, **kw) -> 'CLIPBPETokenizer':
+        '''`directory` holds vocab.json and merges.txt (the layout of the tokenizer/ folder of a
+        diffusers checkpoint, or of the CLIP model repository).'''
+        with open(os.path.join(directory, 'vocab.json'), encoding='utf-8') as f:
+            vocab = json.load(f)
+        with open(os.path.join(directory, 'merges.txt'), encoding='utf-8') as f:
+            merges = f.read().split('\n')
+        cfg = os.path.join(directory, 'tokenizer_config.json')
+        if os.path.exists(cfg) and 'pad_token' not in kw:
+            with open(cfg, encoding='utf-8') as f:
+                pad = json.load(f).get('pad_token')
+            if isinstance(pad, dict):
+                pad = pad.get('content')
+            if isinstance(pad, str) and pad in vocab:
+                kw['pad_token'] = pad
+        return cls(vocab, merges, **kw)
+
+    def _merge(self, piece: str) -> List[str]:
+        got = self._memo.get(piece)
+        if got is not None:
+            return got
+        sym = [self._bytes[b] for b in piece.encode('utf-8')]
+        sym[-1] += '</w>'
+        while len(sym) > 1:
+            best, at = None, -1
+            for i in range(len(sym) - 1):
+                r = self.rank.get((sym[i], sym[i + 1]))
+                if r is not None and (best is None or r < best):
+                    best, at = r, i
+            if best is None:
+                break
+            a, b = sym[at], sym[at + 1]
+            out, i = [], 0
+            while i < len(sym):                      # merge EVERY occurrence of the winning pair
+                if i + 1 < len(sym) and sym[i] == a and sym[i + 1] == b:
+                    out.append(a + b)
+                    i += 2
+                else:
+                    out.append(sym[i])
+                    i += 1
+            sym = out
+        self._memo[piece] = sym
+        return sym
+
+    def tokenize(self, text: str) -> List[str]:
+        text = self._space.sub(' ', unicodedata.normalize('NFC', text)).lower()
+        out: List[str] = []
+        for piece in self._pieces.findall(text):
+            if piece in (self.BOS, self.EOS):
+                out.append(piece)
+            else:
+                out.extend(self._merge(piece))
+        return out
+
+    def encode(self, text: str) -> List[int]:
+        return [self.vocab.get(t, self.unk_token_id) for t in self.tokenize(text)]
+
+    def __call__(self, prompt: Union[str, List[str]], padding='max_length', max_length=None,
+                 truncation=True, return_tensors='pt'):
+        prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+        L = max_length or self.model_max_length
+        rows = []
+        for p in prompts:
+            ids = self.encode(p)
+            if truncation:
+                ids = ids[:L - 2]
+            rows.append([self.bos_token_id] + ids + [self.eos_token_id])
+        width = L if padding == 'max_length' else max(len(r) for r in rows)
+        rows = [r + [self.pad_token_id] * (width - len(r)) for r in rows]
         return SimpleNamespace(input_ids=torch.tensor(rows, dtype=torch.long))
