@@ -64,6 +64,17 @@ def _read_safetensors(path: str) -> Dict[str, torch.Tensor]:
     return out
 
 
+def _read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
+    '''.safetensors, or the torch-pickle .bin files the 2022 repositories shipped (tensors only:
+    `weights_only=True`, nothing else in the pickle is executed).'''
+    if path.endswith('.safetensors'):
+        return _read_safetensors(path)
+    sd = torch.load(path, map_location='cpu', weights_only=True)
+    if not isinstance(sd, dict) or not all(isinstance(v, torch.Tensor) for v in sd.values()):
+        raise ValueError(f'{path} is not a flat name -> tensor state dict')
+    return sd
+
+
 def _fit(sd: Dict[str, torch.Tensor], shapes, what: str) -> Dict[str, torch.Tensor]:
     '''Check a loaded state dict against the architecture's parameter table (names AND shapes;
     a checkpoint of another architecture must fail loudly, not produce noise images).'''
@@ -93,8 +104,8 @@ def load_state_dicts(sd_dir: str, clip_dir: str, preset: str = 'sd15') -> Dict[s
     the reference's `Runner.__init__` downloads (utils.py:24-25, 59-68: "CompVis/stable-
     diffusion-v1-4" and "openai/clip-vit-large-patch14"); there is no network here, so the
     files must already be on disk.  `sd_dir` holds unet/ and vae/ with
-    diffusion_pytorch_model.safetensors, `clip_dir` holds model.safetensors of the full
-    CLIPModel (text + vision tower + projections).  Returns the same {'unet','vae','clip'}
+    diffusion_pytorch_model.safetensors (or .bin), `clip_dir` holds model.safetensors (or
+    pytorch_model.bin) of the full CLIPModel (text + vision tower + projections).  Returns the same {'unet','vae','clip'}
     dict of fp32 CPU tensors as `synthetic_state_dicts`, validated name-by-name and
     shape-by-shape against the preset's architecture.'''
     import os
@@ -106,13 +117,14 @@ def load_state_dicts(sd_dir: str, clip_dir: str, preset: str = 'sd15') -> Dict[s
                 return os.path.join(d, n)
         raise FileNotFoundError(f'none of {names} under {d}')
 
-    st = ('diffusion_pytorch_model.safetensors', 'diffusion_pytorch_model.fp16.safetensors')
+    st = ('diffusion_pytorch_model.safetensors', 'diffusion_pytorch_model.fp16.safetensors',
+          'diffusion_pytorch_model.bin')
     return {
-        'unet': _fit(_read_safetensors(find(os.path.join(sd_dir, 'unet'), st)),
+        'unet': _fit(_read_checkpoint(find(os.path.join(sd_dir, 'unet'), st)),
                      W.unet_param_shapes(ucfg), 'unet'),
-        'vae': _fit(_read_safetensors(find(os.path.join(sd_dir, 'vae'), st)),
+        'vae': _fit(_read_checkpoint(find(os.path.join(sd_dir, 'vae'), st)),
                     W.vae_param_shapes(vcfg), 'vae'),
-        'clip': _fit(_read_safetensors(find(clip_dir, ('model.safetensors',))),
+        'clip': _fit(_read_checkpoint(find(clip_dir, ('model.safetensors', 'pytorch_model.bin'))),
                      W.clip_param_shapes(ccfg), 'clip'),
     }
 

@@ -71,3 +71,27 @@ def test_load_state_dicts_from_safetensors(tmp_path):
             assert torch.equal(got[part][k], sds[part][k]), (part, k)
     with pytest.raises(ValueError, match='does not match the architecture'):
         build.load_state_dicts(str(sd_dir), str(clip_dir), 'sd15')
+
+
+def test_load_state_dicts_from_bin(tmp_path):
+    '''The torch-pickle layout of the 2022 repositories (diffusion_pytorch_model.bin,
+    pytorch_model.bin) loads the same way; a pickle that is not a flat tensor dict is refused.'''
+    import os
+    import pytest
+    import torch
+    from flexdiffuse_amd import build
+    sds = build.synthetic_state_dicts('mini', seed=4)
+    sd_dir, clip_dir = tmp_path / 'sd', tmp_path / 'clip'
+    for sub in ('unet', 'vae'):
+        os.makedirs(sd_dir / sub)
+        torch.save({k: v.half() for k, v in sds[sub].items()}, str(sd_dir / sub / 'diffusion_pytorch_model.bin'))
+    os.makedirs(clip_dir)
+    torch.save(dict(sds['clip']), str(clip_dir / 'pytorch_model.bin'))
+    got = build.load_state_dicts(str(sd_dir), str(clip_dir), 'mini')
+    for k, v in sds['unet'].items():
+        assert got['unet'][k].dtype == torch.float32 and torch.equal(got['unet'][k], v.half().float()), k
+    for k, v in sds['clip'].items():
+        assert torch.equal(got['clip'][k], v), k
+    torch.save({'state_dict': dict(sds['clip'])}, str(clip_dir / 'pytorch_model.bin'))
+    with pytest.raises(ValueError, match='flat name'):
+        build.load_state_dicts(str(sd_dir), str(clip_dir), 'mini')
