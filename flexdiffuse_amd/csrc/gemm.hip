@@ -1497,6 +1497,14 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     int rc;
     if (d->trans_out) {
         fd_prof_begin(FD_FAMILY_GEMM, st, flops);
+        // 128x160 with 8 waves where 160 | N and the rows fill the chip: -16..18 % on the 64x64 / 32x32
+        // self-attention V projections (tools/ab_vt.py; 256x160 / 16 waves is no better, 16x16 maps tie).
+        // FD_GEMM_VT_TILE=0: the 128x64 / 4-wave tile everywhere (A/B)
+        static const int vt_tile = getenv("FD_GEMM_VT_TILE") ? atoi(getenv("FD_GEMM_VT_TILE")) : 9;
+        if (vt_tile && g.N % 160 == 0 && batch == 1 && g.M >= 8192 &&
+            2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K) < 0x7fffffffull)
+            rc = g.ln_stats ? launch_mode<128, 160, true, false, 4, 2, 2, 7>(g, batch, st) : launch_mode<128, 160, true, false, 4, 2, 2, 0>(g, batch, st);
+        else
         rc = g.ln_stats ? launch_mode<128, 64, true, false, 2, 2, 2, 7>(g, batch, st) : launch<128, 64, true>(g, batch, st);
         fd_prof_end(FD_FAMILY_GEMM, st);
         return rc;

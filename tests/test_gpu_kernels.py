@@ -215,6 +215,19 @@ def test_gemm_transposed_store_feeds_attention(dev):
     assert float(vt[:, :, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('B,N,C', [(2, 4100, 320), (4, 4096, 640), (16, 1024, 640)])
+def test_gemm_transposed_store_wide_tile(dev, B, N, C):
+    '''M = B*N >= 8192 with 160 | C takes the 128x160 / 8-wave transposed tile (ragged last row
+    block, padded columns stay zero); FD_GEMM_VT_TILE=0 is the 128x64 tile of the small case above.'''
+    from flexdiffuse_amd import ops
+    x, wv, bv = rnd((B * N, C), 3), rnd((C, C), 4, C ** -0.5), rnd((C,), 5, 0.1)
+    ldv = (N + 7) // 8 * 8 + 8
+    vt = ops.gemm_vt(x.half().to(dev), ops.prep_linear(wv, bv, dev), B, N, ldv)
+    want = (x.half().float() @ wv.half().float().T + bv).view(B, N, C).transpose(1, 2)
+    close(vt[:, :, :N], want, rtol=3e-3, atol=3e-3)
+    assert float(vt[:, :, N:].abs().max()) == 0.0
+
+
 def test_vae_attention_pieces(dev):
     from flexdiffuse_amd import ops
     B, N, C = 2, 256, 512
