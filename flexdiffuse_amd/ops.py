@@ -188,10 +188,11 @@ _splitk_ws = {}
 SPLITK_WS_BYTES = 96 << 20
 FORCE_TILE = 0      # debugging / tuning knobs (0 = library cost model)
 FORCE_SPLIT = 0
+WS_SLOT = 0         # scratch-buffer set; work enqueued concurrently on another stream must use another slot
 
 
 def _sched(d: 'fd_gemm_desc', dev: torch.device):
-    key = dev.index if dev.index is not None else 0
+    key = (dev.index if dev.index is not None else 0, WS_SLOT)
     ws = _splitk_ws.get(key)
     if ws is None:
         ws = torch.empty(SPLITK_WS_BYTES, dtype=torch.uint8, device=dev)
@@ -352,7 +353,7 @@ _gn_ws = {}
 
 def _gn_workspace(B: int, G: int, dev) -> torch.Tensor:
     n = hip.lib().fd_groupnorm_workspace_floats(B, G)
-    key = (dev.index if dev.index is not None else 0)
+    key = (dev.index if dev.index is not None else 0, WS_SLOT)
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < n:
         ws = torch.empty(n, dtype=torch.float32, device=dev)
