@@ -130,6 +130,39 @@ def test_groupnorm(dev, C, HW, silu, eps):
     close(y.t.float().view(B, HW, C).permute(0, 2, 1), want, rtol=3e-3, atol=3e-3)
 
 
+@pytest.mark.parametrize('B,HW,C,silu', [(16, 4096, 320, True), (16, 4096, 640, True), (8, 4096, 320, False),
+                                        (2, 4096, 320, True), (16, 3600, 320, True), (5, 4100, 640, False),
+                                        (16, 4096, 960, True), (1, 16384, 128, True)])
+def test_groupnorm_large_maps(dev, B, HW, C, silu):
+    '''Large maps (the streaming statistics + apply pair, partial sums through the workspace): against
+    torch fp32, then 60 repeats while another stream keeps the chip unevenly busy -- every repeat must
+    reproduce the first bit for bit (fixed-order reductions, no atomics).'''
+    from flexdiffuse_amd import ops
+    gen = torch.Generator().manual_seed(B * 7 + C)
+    x = (torch.randn((B, HW, C), generator=gen) * 1.5 + 0.7 + torch.randn((B, 1, C), generator=gen)).half()
+    g, b = 1 + 0.1 * rnd((C,), 2), 0.1 * rnd((C,), 3)
+    xa = ops.Act(x.reshape(B * HW, C).to(dev).contiguous(), B, HW, 1)
+    y = ops.groupnorm(xa, g.to(dev), b.to(dev), 32, 1e-5, silu)
+    want = F.group_norm(x.float().permute(0, 2, 1), 32, g, b, 1e-5)
+    if silu:
+        want = F.silu(want)
+    close(y.t.float().view(B, HW, C).permute(0, 2, 1), want, rtol=3e-3, atol=3e-3)
+    first = y.t.clone()
+    side = torch.cuda.Stream()
+    a = torch.randn((4096, 1280), device=dev).half()
+    w = ops.prep_linear(torch.randn((1280, 1280)) * 1280 ** -0.5, None, dev)
+    for it in range(60):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                ops.WS_SLOT = 1
+                for _ in range(2 + it % 5):
+                    ops.gemm(a, w)
+                ops.WS_SLOT = 0
+        y = ops.groupnorm(xa, g.to(dev), b.to(dev), 32, 1e-5, silu)
+        assert torch.equal(y.t, first), it
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('C', [128, 320, 768, 1280])
 def test_layernorm(dev, C):
     from flexdiffuse_amd import ops
