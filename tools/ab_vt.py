@@ -1,5 +1,7 @@
-'''A/B of the V^T projection tile (FD_GEMM_VT_TILE = 0 / 9 / 13) on the UNet's self-attention V
-shapes, with and without the LayerNorm fold; each arm is a child process (the knob is read once).
+'''A/B of the V^T projection tile (FD_GEMM_VT_TILE = 0: 128x64 / 4 waves, 9: 128x160 / 8 waves at
+M >= 8192) on the UNet's self-attention V shapes, with and without the LayerNorm fold; each arm is a
+child process (the knob is read once).  The 256x160 / 16-wave arm of the recorded run
+(profiles/r02_session_ab.txt) was removed from the library afterwards.
     python tools/ab_vt.py'''
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,7 +40,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
             us = e0.elapsed_time(e1) * 1e3 / 50
             print(f'  M={M:6d} C={C:5d} fold={fold}: {us:7.1f} us  {2.0 * M * C * C / us / 1e6:6.0f} TFLOP/s  max|err| {err:.4f}', flush=True)
     sys.exit(0)
-for arm in ('0', '9', '13'):
+for arm in ('0', '9'):
     env = dict(os.environ, FD_GEMM_VT_TILE=arm)
     print(f'FD_GEMM_VT_TILE={arm}', flush=True)
     subprocess.run([sys.executable, os.path.abspath(__file__), 'child'], env=env, check=False)
