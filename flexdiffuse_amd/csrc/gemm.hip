@@ -1009,6 +1009,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
                                                                                acc[i][j], 0, 0, 0);
             }
         }
+        // keep the wait for the NEXT K-tile's DMA behind ALL of this tile's MFMAs: left alone, hipcc sinks the second
+        // half of the MFMAs below the wait + barrier (they only touch registers), which halves the cover of the DMA
+        // round trip (ISA of the 256x160 tile; the persistent kernel, whose wait sits behind a branch, was 2.5-5 % faster)
+        // (the VAE's 256x128 / 256x256 tiles are 2 % FASTER with the compiler's own placement: 160-wide tiles only)
+        if constexpr (BN == 160) __builtin_amdgcn_sched_barrier(0);
         if (NS == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1306,7 +1311,7 @@ static int g_vae15 = getenv("FD_GEMM_VAE15") ? atoi(getenv("FD_GEMM_VAE15")) : 1
 static int g_tap_fast = getenv("FD_CONV_TAPFAST") ? atoi(getenv("FD_CONV_TAPFAST")) : 1;   // 1: 256x320 tile, 2: every conv tile
 static int g_bias_lds = getenv("FD_GEMM_BIAS_LDS") ? atoi(getenv("FD_GEMM_BIAS_LDS")) : 1;
 static int g_fast_epi = getenv("FD_GEMM_FAST_EPI") ? atoi(getenv("FD_GEMM_FAST_EPI")) : 1;   // 0: generic epilogue only (A/B)
-// 0 = never, 1 = short-K GEMMs and the 256-row 16-wave tiles (default), 2 = always, 3 = short-K GEMMs only
+// 0 = never, 1 = short-K GEMMs only (default), 2 = always
 static int g_persist_mode = getenv("FD_GEMM_PERSIST") ? atoi(getenv("FD_GEMM_PERSIST")) : 1;
 
 template <int BM, int BN, bool TRANS, bool CONV, int WM = 2, int NS = 2, int WN = 2, int EPI = 0>
@@ -1335,14 +1340,8 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         const int occ = (BM >= 256 || lds > 80 * 1024) ? 1 : (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);  // workgroups / CU
         const int slots = 256 * occ;
         const int nkt = (g.K + BK - 1) / BK / g.split_k;
-        // ... and the 256-row 16-wave tiles (256x160, 256x256) always: their persistent body is 2.5-5 % faster than
-        // the one-tile kernel even with a single tile per workgroup (per-launch trace A/B of FD_GEMM_PERSIST=1 vs 2,
-        // profiles/r02_session_ab.txt: -165 us per UNet forward), except where it would fall back to the generic
-        // epilogue for a per-sample bias
-        const bool wide16 = BM == 256 && (BN == 160 || (BN == 256 && !CONV)) && !TRANS && !(EPI >= 1 && EPI <= 3 && g.bias2);   // (the VAE's 256x256 conv tiles: 2 % slower persistent)
         const bool persistent = NS == 2 && BN != 320 && (g_persist_mode == 2 ||
-                                (g_persist_mode == 1 && (wide16 || (nkt <= 20 && g.tiles_m * g.tiles_n > slots))) ||
-                                (g_persist_mode == 3 && nkt <= 20 && g.tiles_m * g.tiles_n > slots));   // 3: short K only (A/B)
+                                (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots));
         if constexpr (EPI >= 1 && EPI <= 3) {
             // the persistent loop does not stage the per-sample bias: generic epilogue there
             if (persistent && g.bias2) return launch_mode<BM, BN, TRANS, CONV, WM, NS, WN, 0>(g, batch, st);
