@@ -1217,6 +1217,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
                                   : __builtin_amdgcn_mfma_f32_16x16x32_f16(                 \
                                         fb[j], fa[i], acc[i][j], 0, 0, 0);                  \
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first tile's first K-tile (+ bias)
 #pragma clang loop unroll(disable)
     while (t < nb) {
         const int m0 = ld_m0, n0 = ld_n0;
@@ -1224,8 +1225,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // bare barrier: every wave has already waited for its share of this tile's first K-tile (before the loop /
+        // before the previous tile's epilogue).  __syncthreads() would also drain the previous epilogue's global
+        // STORES (vmcnt counts them): a store round trip exposed once per tile
+        __builtin_amdgcn_s_barrier();
         const int t_next = t + gridDim.x;
 #pragma clang loop unroll(disable)
         for (int kt = kt0; kt < nk; ++kt) {
@@ -1241,10 +1244,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
             const char* st = smem + cur * STAGE;
             GEMM_MFMA_TILE(st);
             stage ^= 1;
-            if (!last) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last: the next tile's first K-tile, ahead of the epilogue's stores
+            if (!last) __syncthreads();
         }
         if constexpr (EPI == 0 || EPI == 7)
             gemm_epilogue<BM, BN, TRANS, WM, WN, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z,
