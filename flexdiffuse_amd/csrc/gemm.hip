@@ -146,12 +146,18 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
             bg[jp] = *reinterpret_cast<lds_cf4>(bias_tile + coll + jp * 32 + 16 + fq * 4);
         }
         half_t* Cb = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC + (size_t)row0 * g.ldc + (col0 >> 1);
+        // LNF: (rstd, -mean * rstd) of this lane's row, loaded ONE ROW BLOCK AHEAD: a load issued inside block i is
+        // waited for with vmcnt(0), i.e. together with block i-1's stores -- a load and a store round trip per block
+        floatx2 st_next = {g.alpha, 0.f};
+        if constexpr (LNF) st_next = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)row0);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             half_t* Crow = Cb + (size_t)i * 16 * g.ldc;
             half4 og[NP];
-            floatx2 st = {g.alpha, 0.f};   // LNF: (rstd, -mean * rstd) of this lane's row
-            if constexpr (LNF) st = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)(row0 + i * 16));
+            const floatx2 st = st_next;
+            if constexpr (LNF) {
+                if (i + 1 < MI) st_next = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)(row0 + (i + 1) * 16));
+            }
 #pragma unroll
             for (int jp = 0; jp < NP; ++jp)
 #pragma unroll
@@ -195,6 +201,9 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
         }
         half_t* Cb = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC + (size_t)row0 * g.ldc + col0;
         const half_t* Rb = RES ? g.res + (size_t)z * g.strideRes + (size_t)row0 * g.ldr + col0 + fq * 4 : nullptr;
+        floatx2 st_next = {g.alpha, 0.f};   // LNF: one row block ahead (see the GEGLU branch)
+        if constexpr (LNF) st_next = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)row0);
+        // (the residual rows one block ahead as well: measured neutral and 2-3 spilled VGPRs on the 256x320 tile -- not kept)
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             half_t* Crow = Cb + (size_t)i * 16 * g.ldc;
@@ -205,8 +214,10 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
                 for (int j = 0; j < NI; ++j) rr[j] = *reinterpret_cast<const half4*>(Rrow + j * 16);
             }
             half4 oh[NI];
-            floatx2 st = {g.alpha, 0.f};
-            if constexpr (LNF) st = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)(row0 + i * 16));
+            const floatx2 st = st_next;
+            if constexpr (LNF) {
+                if (i + 1 < MI) st_next = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)(row0 + (i + 1) * 16));
+            }
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
