@@ -172,11 +172,22 @@ __global__ void k_gn_apply(const half_t* __restrict__ x, half_t* __restrict__ y,
     const half_t* xb = x + ((size_t)b * HW) * ldx + cc * 8;
     half_t* yb = y + ((size_t)b * HW) * C + cc * 8;
     int p = p0 + pl;
-    for (; p + 3 * PL < p1; p += 4 * PL) {
-        uint4 raw[4];
+    // software-pipelined: the NEXT group's 4 loads are issued before this group's stores.  Loads issued after
+    // the stores could only be waited for with a vmcnt that also drains those stores (one counter, in order): a
+    // store round trip plus a load round trip per group with only 2 waves per SIMD to hide them
+    uint4 raw[4], nxt[4];
+    bool have = p + 3 * PL < p1;
+    if (have) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            raw[u] = *reinterpret_cast<const uint4*>(xb + (size_t)(p + u * PL) * ldx);
+        for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(xb + (size_t)(p + u * PL) * ldx);
+    }
+    while (have) {
+        const int pn = p + 4 * PL;
+        const bool more = pn + 3 * PL < p1;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nxt[u] = *reinterpret_cast<const uint4*>(xb + (size_t)(pn + u * PL) * ldx);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const half8 v = *reinterpret_cast<const half8*>(&raw[u]);
@@ -185,6 +196,10 @@ __global__ void k_gn_apply(const half_t* __restrict__ x, half_t* __restrict__ y,
             for (int k = 0; k < 8; ++k) o[k] = (half_t)gn_act(fmaf((float)v[k], sc[k], sh[k]), silu);
             *reinterpret_cast<uint4*>(yb + (size_t)(p + u * PL) * C) = *reinterpret_cast<uint4*>(&o);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = nxt[u];
+        p = pn;
+        have = more;
     }
     for (; p < p1; p += PL) {
         const uint4 raw = *reinterpret_cast<const uint4*>(xb + (size_t)p * ldx);
