@@ -193,11 +193,15 @@ __global__ __launch_bounds__(64 * NW, (DQK <= 96 ? 2 : 1)) void k_attention(Attn
         for (int t = 0; t < QT; ++t) {
             const int q = q0 + t * 16 + fr;
             if (need_mask) {
+                // the key base goes through an empty asm INSIDE the branch: hipcc otherwise speculates the whole index /
+                // compare arithmetic (16 v_add + 32 v_cmp per query block) above the branch, into every unmasked tile
+                int kb = j * 64 + g * 4;
+                asm volatile("" : "+v"(kb));
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int key = j * 64 + f * 16 + g * 4 + r;
+                        const int key = kb + f * 16 + r;
                         if (key >= a.Nk || (a.causal && key > q)) s[f][t][r] = -INFINITY;
                     }
             }
@@ -485,11 +489,13 @@ __global__ __launch_bounds__(512, (DV <= 3 ? ATT_W8_MINW : DQK <= 96 ? 2 : 1)) v
         }
         if (need_mask) {
             const int q = q0 + fr;
+            int kb = j * 64 + g * 4;   // opaque inside the branch: see k_attention
+            asm volatile("" : "+v"(kb));
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = j * 64 + f * 16 + g * 4 + r;
+                    const int key = kb + f * 16 + r;
                     if (key >= a.Nk || (a.causal && key > q)) s[f][r] = -INFINITY;
                 }
         }
@@ -778,11 +784,13 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8q2(AttnArgs a) {
             }
             if (need_mask) {
                 const int q = q0 + t * 16 + fr;
+                int kb = j * 64 + g * 4;   // opaque inside the branch: see k_attention
+                asm volatile("" : "+v"(kb));
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int key = j * 64 + f * 16 + g * 4 + r;
+                        const int key = kb + f * 16 + r;
                         if (key >= a.Nk || (a.causal && key > q)) s[t][f][r] = -INFINITY;
                     }
             }
