@@ -32,12 +32,21 @@ __global__ void k_gn_stats(const half_t* __restrict__ x, float* __restrict__ par
     if (pl < PL) {
         const half_t* base = x + ((size_t)b * HW) * ldx + cc * 8;   // ldx: row stride of x (>= C)
         int p = p0 + pl;
-        // 4 independent 16-byte loads in flight per lane (the kernel is latency-bound otherwise)
-        for (; p + 3 * PL < p1; p += 4 * PL) {
-            uint4 raw[4];
+        // 4 independent 16-byte loads per group, and the NEXT group issued before this one is consumed (8 in flight):
+        // with one workgroup per CU the kernel is latency-bound otherwise
+        uint4 raw[4], nxt[4];
+        bool have = p + 3 * PL < p1;
+        if (have) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                raw[u] = *reinterpret_cast<const uint4*>(base + (size_t)(p + u * PL) * ldx);
+            for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(base + (size_t)(p + u * PL) * ldx);
+        }
+        while (have) {
+            const int pn = p + 4 * PL;
+            const bool more = pn + 3 * PL < p1;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) nxt[u] = *reinterpret_cast<const uint4*>(base + (size_t)(pn + u * PL) * ldx);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const half8 v = *reinterpret_cast<const half8*>(&raw[u]);
@@ -48,6 +57,10 @@ __global__ void k_gn_stats(const half_t* __restrict__ x, float* __restrict__ par
                     q[k] = fmaf(f, f, q[k]);
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) raw[u] = nxt[u];
+            p = pn;
+            have = more;
         }
         for (; p < p1; p += PL) {
             const uint4 raw = *reinterpret_cast<const uint4*>(base + (size_t)p * ldx);
