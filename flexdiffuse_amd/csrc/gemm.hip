@@ -1618,7 +1618,9 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     // CU, each a 20..80-deep K loop whose DMA round trip (not the MFMAs) sets the pace -- a third LDS
     // stage (two K-tiles in flight) gives -10 % at K = 1280, -22 % at K = 2560 (vs 256x160 + split-K 2),
     // -3 % at K = 5120 (tools/ab_ns3.py).  Convolutions and M >= 16 k lose with it (one workgroup per CU).
-    if (g.mode != MODE_CONV && n160 && g.M > 2048 && g.M <= 4096 && g.K >= 1280 && batch == 1) {
+    // ... unless 256x160 tiles already give every CU one tile (N = 2560, the fused q|k projection: 33 vs 41.5 us)
+    if (g.mode != MODE_CONV && n160 && g.M > 2048 && g.M <= 4096 && g.K >= 1280 && batch == 1 &&
+        (long long)fd_cdiv(g.M, 256) * (g.N / 160) < 256) {
         best_tile = 20;
         best_split = 1;
     }
