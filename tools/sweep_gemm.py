@@ -28,8 +28,8 @@ torch.cuda.synchronize()
 hip.call = orig_call; ops.hip.call = orig_call
 del unet, vae, sds
 print('unique shapes', len(rec))
-def timeit(fn, n=5):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, n=8):
+    fn(); fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
@@ -70,12 +70,13 @@ for key, cnt in rec.items():
     t_auto = timeit(lambda: run(0, 0))
     best = (1e9, None)
     row = {}
-    for tile in (1,2,3,4,6,9,10,11,12,13,14):
-        if act == 4 and tile in (2,5,7,9,12,13): continue
+    for tile in (1,2,3,4,6,9,10,11,12,13,14,15,16,20):
+        if act == 4 and tile in (2,5,7,9,12,13,16,20): continue
+        if tile in (15,16) and N % (256 if tile == 15 else 320): continue
         for sk in (1,2,4,8,16):
             if sk > 1 and (act == 4 or (K//64)//sk < 4 or sk*M*N*4 > ws.numel()): continue
             try:
-                t = timeit(lambda: run(tile, sk), n=3)
+                t = timeit(lambda: run(tile, sk), n=6)
             except Exception as e:
                 continue
             row[(tile,sk)] = t
