@@ -29,8 +29,9 @@ import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
+# numpy / torch are imported inside the functions that need them: the parent of an N-rank run
+# (launch_ranks) starts its children with the standard library only and never loads the HIP
+# runtime -- a process that has touched the GPU must not be the one that spawns the ranks.
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -64,14 +65,17 @@ REFERENCE_GUIDANCE_STAGE = {
 }
 
 
-def flops_per_image(preset, size, steps):
+def flops_per_image(preset, size, evals):
+    '''2 UNet forwards (CFG) per executed DDIM evaluation + one VAE decode (img2img runs
+    int(steps * strength) evaluations and its one VAE encode per CALL is not priced).'''
     u, v = UNET_GFLOP.get((preset, size)), VAE_TFLOP.get(size)
     if u is None or v is None:
         return None
-    return 2 * steps * u * 1e9 + v * 1e12
+    return 2 * evals * u * 1e9 + v * 1e12
 
 
 def synth_image(seed, w, h):
+    import numpy as np
     from PIL import Image
     rng = np.random.default_rng(seed)
     a = rng.integers(0, 256, (h + 8, w + 8, 3)).astype(np.float32)
@@ -82,6 +86,7 @@ def synth_image(seed, w, h):
 
 
 def synth_prompts(n, seed=1):
+    import numpy as np
     rng = np.random.default_rng(seed)
     words = ['photo', 'turtle', 'forest', 'zeus', 'city', 'painting', 'deer', 'storm', 'neon',
              'ancient', 'river', 'portrait', 'rock', 'monkey', 'anime', 'golden', 'light']
@@ -92,6 +97,7 @@ def cpu_baseline(sds, cfgs, steps, size):
     '''Oracle (torch fp32 restatement of the reference path) timed on the host cores over a
     bounded sample: one CFG UNet evaluation (2 forwards) of ONE image plus one VAE decode,
     extrapolated to steps x UNet + decode per image.'''
+    import torch
     from oracle import unet_ref, vae_ref
     ucfg, vcfg, _ = cfgs
     g = torch.Generator().manual_seed(0)
@@ -116,6 +122,7 @@ def cpu_baseline(sds, cfgs, steps, size):
 def parity_c1(sds, cfgs, pipe, enc, tok, steps=10, hw=256, guidance=8.0):
     '''BASELINE configs[0] shape (256x256, 10 DDIM steps, batch 1, CFG 8) on the same SD1.5
     weights: GPU fp16 path vs the CPU fp32 oracle with identical ids and CPU-drawn noise.'''
+    import torch
     from flexdiffuse_amd import SimpleGuide
     from oracle import clip_ref, pipeline_ref
     ucfg, vcfg, ccfg = cfgs
@@ -145,6 +152,8 @@ def parity_c2(sds, cfgs, pipe, guide_ctx, enc):
     of the same sample, cached in tests/golden/c2_oracle.npz by tests/golden/make_c2_oracle.py
     (100 fp32 UNet forwards, ~13 min on 8 cores); only the oracle's VAE decode runs here.'''
     import hashlib
+    import numpy as np
+    import torch
     path = os.path.join(ROOT, 'tests', 'golden', 'c2_oracle.npz')
     if not os.path.exists(path):
         return None
@@ -184,6 +193,7 @@ EVENT_STRIDE = 7
 def best_kernel_leg(dev):
     '''The level-0 ResBlock conv3x3 (16 x 64 x 64 x 320 -> 320, 120.8 GFLOP, the largest single
     share of the pass) timed alone: 20 launches between two events on the launch stream.'''
+    import torch
     from flexdiffuse_amd import ops
     g = torch.Generator().manual_seed(3)
     x = ops.Act((torch.randn((16 * 4096, 320), generator=g) * 0.5).half().to(dev), 16, 64, 64)
@@ -210,26 +220,97 @@ def _free_port():
 
 
 def launch_ranks(n: int) -> int:
-    '''Parent of an N-rank run: starts N fresh children BEFORE any GPU call in this process
-    (device_count() does not initialise the GPU), one rank per GPU over RCCL.'''
-    visible = torch.cuda.device_count()
-    share = os.environ.get('FD_BENCH_SHARE_GPU') == '1'   # plumbing test: several ranks on one GPU
-    if visible < n and not (share and visible >= 1):
-        print(f'bench.py: --gpus {n} but only {visible} device(s) visible', file=sys.stderr)
-        return 2
+    '''Parent of an N-rank run: starts N fresh children, one rank per GPU over RCCL, relays
+    rank 0's line and returns the worst child status.  Standard library only -- this process
+    never imports torch, never counts devices through HIP and never touches the GPU; each child
+    checks for itself that its device exists (`--gpus N` with fewer than N visible devices makes
+    every child exit 2 before the rendezvous).  A child that dies takes the others down with it
+    instead of leaving them in the rendezvous.'''
     port = _free_port()
+    threads = max(1, (os.cpu_count() or n) // n)      # host threads of torch's CPU ops per rank
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % visible if share else r),
-                   WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        env.setdefault('OMP_NUM_THREADS', str(threads))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                       env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for i, p in enumerate(procs):          # exactly the processes started above
+                if rcs[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[i] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write((out[0] if out else b'').decode())
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
+
+
+def check_rank_device(local_rank: int, world: int) -> int:
+    '''Device ordinal of this rank, or exit 2: no silent fallback to fewer GPUs.
+    FD_BENCH_SHARE_GPU=1 (plumbing tests on a 1-GPU box) lets several ranks share devices.'''
+    import torch
+    visible = torch.cuda.device_count()
+    share = os.environ.get('FD_BENCH_SHARE_GPU') == '1'
+    if visible < 1 or (visible < world and not share):
+        print(f'bench.py: --gpus {world} but only {visible} device(s) visible', file=sys.stderr)
+        sys.exit(2)
+    return local_rank % visible
+
+
+def plumbing_rank(args) -> None:
+    '''FD_BENCH_PLUMBING=1 (tests only, never a bench result): what a rank does AROUND the hot
+    path -- join the process group, take its shard of prompts and of the host-drawn noise, gather,
+    max-reduce the clock -- with no GPU work in between, so that the N-rank launcher and the
+    sharding can be exercised where no GPU exists.  The line says so in `metric` and `data`.'''
+    import torch
+    import torch.distributed as dist
+    from flexdiffuse_amd import dist as fdist
+    rank, world, _ = fdist.init('gloo')
+    B = args.batch
+    prompts = fdist.shard(synth_prompts(B * world), rank, world, B)
+    h = args.size // 8
+    noise = fdist.global_noise(B * world, (4, h, h), 1337)
+    mine = noise[fdist.shard_range(rank, world, B)]
+    if dist.is_initialized():
+        dist.barrier()
+    t0 = time.time()
+    gathered = fdist.all_gather_samples(mine)
+    elapsed = time.time() - t0
+    if dist.is_initialized():
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ok = bool(torch.equal(gathered, noise)) and len(prompts) == B
+    if rank == 0:
+        print(json.dumps({'metric': 'plumbing-only (launcher + sharding + gather; NOT a benchmark)',
+                          'value': 0.0, 'unit': 'images/sec', 'n_gpus': world, 'steps': 0, 'warmup': 0,
+                          'data': 'plumbing-only (no GPU work)', 'rccl_ranks': 0,
+                          'gather_equals_global_batch': ok, 'gather_ms': 1e3 * elapsed,
+                          'backend': dist.get_backend() if dist.is_initialized() else 'none',
+                          'omp_num_threads': os.environ.get('OMP_NUM_THREADS')}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
 
 
 def main():
@@ -245,6 +326,14 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the UNet from a captured HIP graph')
+    ap.add_argument('--launch', default='plan', choices=['plan', 'eager'],
+                    help='plan (default): the UNet forward is replayed from its recorded launch plan '
+                         '(same kernels, same order, eager launches, no per-op host work); eager: every '
+                         'op goes through the Python front each step')
+    ap.add_argument('--img2img', action='store_true',
+                    help='BASELINE configs[3] (c4): start from a synthetic init image of --size, '
+                         '--strength 0.6 => int(steps * strength) UNet evaluations (pipeline/flex.py:181-221)')
+    ap.add_argument('--strength', type=float, default=0.6)
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -253,7 +342,11 @@ def main():
     if env_world != args.gpus:
         print(f'bench.py: --gpus {args.gpus} does not match WORLD_SIZE={env_world}', file=sys.stderr)
         sys.exit(2)
+    if os.environ.get('FD_BENCH_PLUMBING') == '1':
+        plumbing_rank(args)
 
+    import torch
+    os.environ['LOCAL_RANK'] = str(check_rank_device(int(os.environ.get('LOCAL_RANK', '0')), env_world))
     import torch.distributed as dist
     from flexdiffuse_amd import dist as fdist
     rank, world, local_rank = fdist.init('nccl')
@@ -271,8 +364,9 @@ def main():
     t_setup = time.time()
     sds = build.synthetic_state_dicts(args.preset, seed=0)
     cfgs = build.configs(args.preset)
-    pipe, clip, tok = build.build_models(sds, args.preset, dev, vae_encoder=False)
+    pipe, clip, tok = build.build_models(sds, args.preset, dev, vae_encoder=args.img2img)
     pipe.use_graph = args.graph
+    pipe.use_plan = args.launch == 'plan' and not args.graph
     guide_ctx = Guide(clip, tok, device='cuda')
     enc = CLIPEncoder(clip, tok)
     B, N = args.batch, world
@@ -282,13 +376,27 @@ def main():
     # the whole global batch of noise is drawn once on the host and sliced per rank, so the
     # images do not depend on the number of GPUs
     noise = fdist.global_noise(B * N, (4, hw // 8, hw // 8), 1337)[fdist.shard_range(rank, N, B)].to(dev)
+    init_image = None
+    if args.img2img:
+        # c4: the (1,3,H,W) tensor in [-1,1] the pipeline takes when it is not handed a PIL image
+        # (`preprocess` would resize a PIL image's long side to 512, encode/clip.py:15-39)
+        sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+        from make_c45_oracle import init_tensor
+        init_image = init_tensor(3, hw).to(dev)
+    ddim_evals = args.ddim_steps if not args.img2img else min(int(args.ddim_steps * args.strength), args.ddim_steps)
     t_setup = time.time() - t_setup
     gather = {'bytes_per_rank': 0, 'ms': 0.0, 'calls': 0}
 
     def one_pass(time_gather=False):
         embeds = guide_ctx.embeds(prompt=prompts, guide=guide_img, **GUIDANCE[args.guidance])
         sg = SimpleGuide(enc, pipe.unet, 8.0, args.ddim_steps, embeds)
-        out = pipe(guide=sg, init_size=(hw, hw), latents=noise, output_type='np')
+        if init_image is not None:
+            # img2img: VAE-encode the init image once, posterior sample and noise from a CPU
+            # generator (rank-offset seed: every rank draws its own B samples), t_start from strength
+            out = pipe(guide=sg, init_image=init_image, strength=args.strength,
+                       generator=torch.Generator('cpu').manual_seed(1337 + rank), output_type='np')
+        else:
+            out = pipe(guide=sg, init_size=(hw, hw), latents=noise, output_type='np')
         # one RCCL all-gather of the final latents and of the decoded images (identity at N=1)
         if time_gather:
             torch.cuda.synchronize()
@@ -322,6 +430,31 @@ def main():
                             device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # ---- host margin: host time to ISSUE one CFG UNet forward vs device time to run it (the
+    # device is fed as long as the host is the faster of the two)
+    margin = None
+    if rank == 0:
+        sg = SimpleGuide(enc, pipe.unet, 8.0, args.ddim_steps,
+                         guide_ctx.embeds(prompt=prompts, guide=guide_img, **GUIDANCE[args.guidance]))
+        lat_m = pipe.loop_latents(noise)
+        ctx_m = sg.stacked_embeds()
+        for _ in range(2):
+            pipe._unet_eps(lat_m, 500, ctx_m, 2)
+        torch.cuda.synchronize()
+        n_m = 5
+        tm0 = time.time()
+        for i in range(n_m):
+            pipe._unet_eps(lat_m, 480 - 20 * i, ctx_m, 2)
+        tm1 = time.time()
+        torch.cuda.synchronize()
+        tm2 = time.time()
+        margin = {'host_ms_per_forward': 1e3 * (tm1 - tm0) / n_m,
+                  'device_ms_per_forward': 1e3 * (tm2 - tm0) / n_m,
+                  'launch': 'graph' if pipe.use_graph else ('plan' if pipe.use_plan else 'eager'),
+                  'launches_per_forward': pipe.plan_launches(),
+                  'note': 'issue time of 5 back-to-back CFG UNet forwards vs their completion time'}
+        margin['host_over_device'] = margin['host_ms_per_forward'] / margin['device_ms_per_forward']
 
     # ---- roofline leg: one extra UNTIMED pass with HIP events on the launch stream around every
     # EVENT_STRIDE-th launch of each kernel family (a pair of event records costs stream time, so
@@ -364,26 +497,35 @@ def main():
                 break
             except (OSError, KeyError, ValueError):
                 continue
-        fpi = flops_per_image(args.preset, hw, args.ddim_steps)
+        fpi = flops_per_image(args.preset, hw, ddim_evals)
         headline = (args.preset == 'sd15' and hw == 512 and args.ddim_steps == 50
-                    and args.guidance == 'linear' and B == 8)
-        cfg_name = {('sd15', 'linear'): 'BASELINE configs[1]',
-                    ('sd15', 'clustered_threshold'): 'BASELINE configs[2] guidance',
-                    ('sd21', 'linear'): 'BASELINE configs[4]'}.get((args.preset, args.guidance), 'non-headline')
+                    and args.guidance == 'linear' and B == 8 and not args.img2img)
+        cfg_name = {('sd15', 'linear', False): 'BASELINE configs[1]',
+                    ('sd15', 'clustered_threshold', False): 'BASELINE configs[2] guidance',
+                    ('sd15', 'linear', True): 'BASELINE configs[3]',
+                    ('sd21', 'linear', False): 'BASELINE configs[4]'}.get(
+                        (args.preset, args.guidance, args.img2img), 'non-headline')
         model = {'sd15': 'SD1.5', 'sd21': 'SD2.1 + OpenCLIP ViT-H/14 guide'}.get(args.preset, args.preset)
+        mode = (f'img2img strength {args.strength} ({ddim_evals} of {args.ddim_steps} DDIM steps)'
+                if args.img2img else f'{args.ddim_steps}-step DDIM')
         line = {
             'metric': '512x512 50-step images/sec/node (SD1.5, batch=8/GPU, Linear image guidance)'
-                      if headline else f'{hw}x{hw} {args.ddim_steps}-step images/sec/node ({model}, '
+                      if headline else f'{hw}x{hw} {mode} images/sec/node ({model}, '
                                        f'batch={B}/GPU, {args.guidance} image guidance)',
             'value': value, 'unit': 'images/sec', 'n_gpus': N, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp16',
             'data': 'synthetic',
-            'config': {'workload': f'{model} {hw}x{hw} {args.ddim_steps}-step DDIM + {args.guidance} image '
+            'config': {'workload': f'{model} {hw}x{hw} {mode} + {args.guidance} image '
                                    f'guidance, CFG 8, batch={B}/GPU ({cfg_name})',
                        'images_per_step': B * N, 'parallelism': f'seed-sharded x{N}',
-                       'preset': args.preset, 'guidance': args.guidance},
-            'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 0,
+                       'preset': args.preset, 'guidance': args.guidance, 'img2img': args.img2img,
+                       'unet_evaluations_per_image': ddim_evals, 'launch': margin['launch']},
+            # ranks that took part in an RCCL (torch.distributed "nccl") process group; 0 for any
+            # other backend (gloo plumbing runs) and for an undistributed N=1 run
+            'rccl_ranks': dist.get_world_size() if dist.is_initialized() and dist.get_backend() == 'nccl' else 0,
+            'dist_backend': dist.get_backend() if dist.is_initialized() else None,
+            'host_margin': margin, 'host_ms_per_forward': margin['host_ms_per_forward'],
             'all_gather': {'bytes_per_rank': gather['bytes_per_rank'],
                            'ms': gather['ms'] / max(gather['calls'], 1),
                            'backend': ('RCCL (torch.distributed nccl)' if dist.get_backend() == 'nccl'

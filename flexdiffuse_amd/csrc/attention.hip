@@ -889,6 +889,10 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8q2(AttnArgs a) {
 
 
 extern "C" int fd_attention_f16(const fd_attention_desc* d, void* stream) {
+    if (fd_plan_recording() && d) {
+        const fd_attention_desc dc_ = *d;
+        fd_plan_push([dc_](void* fd_s_) -> int { return fd_attention_f16(&dc_, fd_s_); });
+    }
     FD_CHECK_ARG(d && d->Q && d->K && d->Vt && d->O, FD_EINVAL, "fd_attention_f16: null pointer");
     FD_CHECK_ARG(d->batch > 0 && d->heads > 0 && d->n_q > 0 && d->n_k > 0, FD_EINVAL,
                  "fd_attention_f16: non-positive dimension");

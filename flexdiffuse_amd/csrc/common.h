@@ -37,6 +37,20 @@ void fd_set_error(const char* fmt, ...);
 
 static inline int fd_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- launch plan (fd_plan_*, runtime.hip): while the calling thread records, every launch entry
+// point appends a by-value copy of its own call (stream left open) to the plan.  FD_PLAN(call)
+// sits at the top of an entry point; `fd_s_` names the stream the replay passes in.
+#ifdef __cplusplus
+#include <functional>
+bool fd_plan_recording();
+void fd_plan_push(std::function<int(void*)> op);
+#define FD_PLAN(...)                                                            \
+    do {                                                                        \
+        if (fd_plan_recording())                                                \
+            fd_plan_push([=](void* fd_s_) -> int { return __VA_ARGS__; });      \
+    } while (0)
+#endif
+
 // optional per-launch HIP-event timing of a kernel family (bench.py roofline leg)
 void fd_prof_begin(int family, hipStream_t s, double work);
 void fd_prof_end(int family, hipStream_t s);

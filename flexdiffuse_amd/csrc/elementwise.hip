@@ -22,6 +22,7 @@ __global__ void k_nchw_to_nhwc(const float* __restrict__ x, half_t* __restrict__
 
 extern "C" int fd_nchw_f32_to_nhwc_f16(const float* x, void* y, int B, int C, int HW, int rep,
                                        int c_pad, float scale, void* stream) {
+    FD_PLAN(fd_nchw_f32_to_nhwc_f16(x, y, B, C, HW, rep, c_pad, scale, fd_s_));
     FD_CHECK_ARG(x && y && B > 0 && C > 0 && HW > 0 && rep > 0 && c_pad >= C, FD_EINVAL,
                  "fd_nchw_f32_to_nhwc_f16: args");
     const size_t total = (size_t)B * HW * c_pad;
@@ -50,6 +51,7 @@ __global__ void k_nhwc_to_nchw(const float* __restrict__ x, float* __restrict__ 
 
 extern "C" int fd_nhwc_f32_to_nchw_f32(const float* x, float* y, int B, int C, int HW, int ld,
                                        float a, float b, int clamp01, void* stream) {
+    FD_PLAN(fd_nhwc_f32_to_nchw_f32(x, y, B, C, HW, ld, a, b, clamp01, fd_s_));
     FD_CHECK_ARG(x && y && B > 0 && C > 0 && HW > 0 && ld >= C, FD_EINVAL,
                  "fd_nhwc_f32_to_nchw_f32: args");
     const size_t total = (size_t)B * C * HW;
@@ -89,6 +91,7 @@ __global__ void k_im2col(const half_t* __restrict__ x, half_t* __restrict__ y, i
 extern "C" int fd_im2col_f16(const void* x, void* y, int B, int Hi, int Wi, int Cin, int Ho,
                              int Wo, int KH, int KW, int stride, int pad_t, int pad_l, int k_pad,
                              void* stream) {
+    FD_PLAN(fd_im2col_f16(x, y, B, Hi, Wi, Cin, Ho, Wo, KH, KW, stride, pad_t, pad_l, k_pad, fd_s_));
     FD_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Ho > 0 && Wo > 0, FD_EINVAL,
                  "fd_im2col_f16: args");
     FD_CHECK_ARG(k_pad >= KH * KW * Cin && k_pad % 8 == 0, FD_ESHAPE, "fd_im2col_f16: k_pad");
@@ -115,6 +118,7 @@ __global__ void k_concat(const uint4* __restrict__ a, const uint4* __restrict__ 
 
 extern "C" int fd_concat_channels_f16(const void* a, const void* b, void* out, int64_t M, int Ca,
                                       int Cb, void* stream) {
+    FD_PLAN(fd_concat_channels_f16(a, b, out, M, Ca, Cb, fd_s_));
     FD_CHECK_ARG(a && b && out && M > 0, FD_EINVAL, "fd_concat_channels_f16: args");
     FD_CHECK_ARG(Ca % 8 == 0 && Cb % 8 == 0, FD_ESHAPE, "fd_concat_channels_f16: C %% 8");
     const size_t total = (size_t)M * (Ca + Cb) / 8;
@@ -122,6 +126,36 @@ extern "C" int fd_concat_channels_f16(const void* a, const void* b, void* out, i
     hipLaunchKernelGGL(k_concat, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)a,
                        (const uint4*)b, (uint4*)out, (size_t)M, Ca / 8, Cb / 8);
     FD_CHECK_LAUNCH("k_concat");
+    return FD_OK;
+}
+
+// ---- strided 2-D copy of fp16 rows (16-byte granules): dst[r][0..cols) = src[r][0..cols) ---------
+// The CFG fan-out of the shared UNet prefix (B samples -> rep*B) and the skip tensors copied into
+// their concat buffers; a library launch (not a torch op) so that a launch plan records it.
+__global__ void k_copy2d(const uint4* __restrict__ src, size_t lds8, uint4* __restrict__ dst, size_t ldd8,
+                         size_t rows, int cols8) {
+    const size_t total = rows * cols8;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int c = e % cols8;
+        const size_t r = e / cols8;
+        dst[r * ldd8 + c] = src[r * lds8 + c];
+    }
+}
+
+extern "C" int fd_copy2d_f16(const void* src, int lds, void* dst, int ldd, int64_t rows, int cols,
+                             void* stream) {
+    FD_PLAN(fd_copy2d_f16(src, lds, dst, ldd, rows, cols, fd_s_));
+    FD_CHECK_ARG(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, FD_EINVAL,
+                 "fd_copy2d_f16: args");
+    FD_CHECK_ARG(cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && (uintptr_t)src % 16 == 0 &&
+                     (uintptr_t)dst % 16 == 0,
+                 FD_ESHAPE, "fd_copy2d_f16: cols / strides must be multiples of 8 and the pointers 16-byte aligned");
+    const size_t total = (size_t)rows * (cols / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_copy2d, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src,
+                       (size_t)(lds / 8), (uint4*)dst, (size_t)(ldd / 8), (size_t)rows, cols / 8);
+    FD_CHECK_LAUNCH("k_copy2d");
     return FD_OK;
 }
 
@@ -166,6 +200,7 @@ extern "C" int fd_cfg_ddim_step_f32(float* x, const float* eps_nhwc, float* eps_
                                     int HW, int ld, int cfg, float guidance, float c1, float c2,
                                     float c3, float c4, int v_prediction, int do_step,
                                     void* stream) {
+    FD_PLAN(fd_cfg_ddim_step_f32(x, eps_nhwc, eps_out, B, C, HW, ld, cfg, guidance, c1, c2, c3, c4, v_prediction, do_step, fd_s_));
     FD_CHECK_ARG(eps_nhwc && B > 0 && C > 0 && HW > 0 && ld >= C, FD_EINVAL,
                  "fd_cfg_ddim_step_f32: args");
     FD_CHECK_ARG(!do_step || x, FD_EINVAL, "fd_cfg_ddim_step_f32: x is null");
@@ -191,6 +226,7 @@ __global__ void k_axpby(const float* __restrict__ x, const float* __restrict__ y
 
 extern "C" int fd_axpby_f32(const float* x, const float* y, float* out, int64_t n, float a,
                             float b, int exp_half_x, void* stream) {
+    FD_PLAN(fd_axpby_f32(x, y, out, n, a, b, exp_half_x, fd_s_));
     FD_CHECK_ARG(x && out && n > 0, FD_EINVAL, "fd_axpby_f32: args");
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_axpby, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, out,
@@ -215,6 +251,7 @@ __global__ void k_embed_tokens(const long long* __restrict__ ids, const half_t* 
 
 extern "C" int fd_embed_tokens_f16(const int64_t* ids, const void* tok_emb, const void* pos_emb,
                                    void* out, int B, int L, int D, int vocab, void* stream) {
+    FD_PLAN(fd_embed_tokens_f16(ids, tok_emb, pos_emb, out, B, L, D, vocab, fd_s_));
     FD_CHECK_ARG(ids && tok_emb && pos_emb && out && B > 0 && L > 0 && D > 0, FD_EINVAL,
                  "fd_embed_tokens_f16: args");
     hipLaunchKernelGGL(k_embed_tokens, dim3(B * L), dim3(256), 0, (hipStream_t)stream,
@@ -238,6 +275,7 @@ __global__ void k_vit_assemble(const half_t* __restrict__ patches, const half_t*
 
 extern "C" int fd_vit_assemble_f16(const void* patches, const void* cls, const void* pos, void* out,
                                    int B, int T, int D, void* stream) {
+    FD_PLAN(fd_vit_assemble_f16(patches, cls, pos, out, B, T, D, fd_s_));
     FD_CHECK_ARG(patches && cls && pos && out && B > 0 && T > 1 && D > 0, FD_EINVAL,
                  "fd_vit_assemble_f16: args");
     hipLaunchKernelGGL(k_vit_assemble, dim3(B * T), dim3(256), 0, (hipStream_t)stream,
@@ -248,10 +286,11 @@ extern "C" int fd_vit_assemble_f16(const void* patches, const void* cls, const v
 }
 
 // ---- sinusoidal timestep embedding (flip_sin_to_cos, shift 0): [cos | sin] -> fp16 -----------
-__global__ void k_timestep_embedding(const float* __restrict__ t, half_t* __restrict__ out, int dim) {
+__global__ void k_timestep_embedding(const float* __restrict__ t, int t_stride, half_t* __restrict__ out,
+                                     int dim) {
     const int b = blockIdx.x;
     const int half_dim = dim / 2;
-    const float tv = t[b];
+    const float tv = t[(size_t)b * t_stride];
     for (int i = threadIdx.x; i < half_dim; i += blockDim.x) {
         const float freq = expf(-9.210340371976184f * (float)i / (float)half_dim);
         const float a = tv * freq;
@@ -260,10 +299,12 @@ __global__ void k_timestep_embedding(const float* __restrict__ t, half_t* __rest
     }
 }
 
-extern "C" int fd_timestep_embedding_f16(const float* t, void* out, int B, int dim, void* stream) {
-    FD_CHECK_ARG(t && out && B > 0 && dim > 0 && dim % 2 == 0, FD_EINVAL,
-                 "fd_timestep_embedding_f16: args");
-    hipLaunchKernelGGL(k_timestep_embedding, dim3(B), dim3(256), 0, (hipStream_t)stream, t,
+extern "C" int fd_timestep_embedding_f16(const float* t, int t_stride, void* out, int B, int dim,
+                                         void* stream) {
+    FD_PLAN(fd_timestep_embedding_f16(t, t_stride, out, B, dim, fd_s_));
+    FD_CHECK_ARG(t && out && B > 0 && dim > 0 && dim % 2 == 0 && (t_stride == 0 || t_stride == 1),
+                 FD_EINVAL, "fd_timestep_embedding_f16: args");
+    hipLaunchKernelGGL(k_timestep_embedding, dim3(B), dim3(256), 0, (hipStream_t)stream, t, t_stride,
                        (half_t*)out, dim);
     FD_CHECK_LAUNCH("k_timestep_embedding");
     return FD_OK;
@@ -277,6 +318,7 @@ __global__ void k_cast(const float* __restrict__ x, half_t* __restrict__ y, size
 }
 
 extern "C" int fd_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream) {
+    FD_PLAN(fd_cast_f32_to_f16(x, y, n, fd_s_));
     FD_CHECK_ARG(x && y && n > 0, FD_EINVAL, "fd_cast_f32_to_f16: args");
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_cast, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (half_t*)y,
@@ -292,6 +334,7 @@ __global__ void k_cast_back(const half_t* __restrict__ x, float* __restrict__ y,
 }
 
 extern "C" int fd_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream) {
+    FD_PLAN(fd_cast_f16_to_f32(x, y, n, fd_s_));
     FD_CHECK_ARG(x && y && n > 0, FD_EINVAL, "fd_cast_f16_to_f32: args");
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_cast_back, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
@@ -315,6 +358,7 @@ __global__ void k_region_blend(float* __restrict__ dst, const float* __restrict_
 
 extern "C" int fd_region_blend_f32(float* dst, const float* src, int C, int H, int W, int oy, int ox,
                                    int sh, int sw, float blend, void* stream) {
+    FD_PLAN(fd_region_blend_f32(dst, src, C, H, W, oy, ox, sh, sw, blend, fd_s_));
     FD_CHECK_ARG(dst && src && C > 0 && H > 0 && W > 0, FD_EINVAL, "fd_region_blend_f32: args");
     // the host resolves Python's slice semantics (a negative start counts from the end of the
     // axis: composition/guide.py:86-98) before calling; here only the clip at the far edge remains

@@ -1469,6 +1469,10 @@ static int launch_epi(GemmArgs& g, int batch, hipStream_t st) {
 }
 
 extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
+    if (fd_plan_recording() && d) {
+        const fd_gemm_desc dc_ = *d;
+        fd_plan_push([dc_](void* fd_s_) -> int { return fd_gemm_f16(&dc_, fd_s_); });
+    }
     FD_CHECK_ARG(d && d->A && d->W && d->C, FD_EINVAL, "fd_gemm_f16: null pointer");
     FD_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, FD_EINVAL, "fd_gemm_f16: M/N/K must be > 0");
     FD_CHECK_ARG(d->K % 8 == 0 && d->ldw % 8 == 0, FD_ESHAPE,

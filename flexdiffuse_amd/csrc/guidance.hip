@@ -522,6 +522,7 @@ static int launch_tween(const float* sim, const float* base, const float* alt, c
 extern "C" int fd_guidance_map(const float* alt, const float* txt, float* ws, int32_t* idx,
                                float* s, int B, int alt_batched, int N, int L, int D, int order,
                                int reuse, void* stream) {
+    FD_PLAN(fd_guidance_map(alt, txt, ws, idx, s, B, alt_batched, N, L, D, order, reuse, fd_s_));
     int rc = check_shapes(B, N, L, D, "fd_guidance_map");
     if (rc) return rc;
     FD_CHECK_ARG(alt && txt && ws && idx && s, FD_EINVAL, "fd_guidance_map: null pointer");
@@ -542,6 +543,12 @@ extern "C" int fd_guidance_tween(const float* base, const float* alt, const floa
                                  float* ws, float* out, float* weights, int32_t* idx, float* s,
                                  int32_t* status, int B, int alt_batched, int N, int L, int D,
                                  const fd_tween_params* p, void* stream) {
+    if (fd_plan_recording() && p) {
+        const fd_tween_params pc_ = *p;
+        fd_plan_push([=](void* fd_s_) -> int {
+            return fd_guidance_tween(base, alt, lin_w, ws, out, weights, idx, s, status, B, alt_batched, N, L, D, &pc_, fd_s_);
+        });
+    }
     int rc = check_shapes(B, N, L, D, "fd_guidance_tween");
     if (rc) return rc;
     FD_CHECK_ARG(base && alt && lin_w && ws && out && weights && idx && s && status && p,
@@ -559,6 +566,7 @@ extern "C" int fd_guidance_tween(const float* base, const float* alt, const floa
 extern "C" int fd_guidance_concept_override(const float* guide, const int32_t* cm_idx,
                                             const int32_t* ct_idx, const float* ct_s, float* out,
                                             int N, int L, int D, void* stream) {
+    FD_PLAN(fd_guidance_concept_override(guide, cm_idx, ct_idx, ct_s, out, N, L, D, fd_s_));
     FD_CHECK_ARG(guide && cm_idx && ct_idx && ct_s && out, FD_EINVAL,
                  "fd_guidance_concept_override: null pointer");
     FD_CHECK_ARG(N > 0 && L > 1 && D > 0, FD_EINVAL, "fd_guidance_concept_override: bad dims");
@@ -570,6 +578,7 @@ extern "C" int fd_guidance_concept_override(const float* guide, const int32_t* c
 
 extern "C" int fd_guidance_header_pull(float* out, const float* hdr, int B, int L, int D,
                                        void* stream) {
+    FD_PLAN(fd_guidance_header_pull(out, hdr, B, L, D, fd_s_));
     FD_CHECK_ARG(out && hdr && B > 0 && L > 0 && D > 0, FD_EINVAL, "fd_guidance_header_pull");
     hipLaunchKernelGGL(k_header_pull, dim3(B), dim3(256), 0, (hipStream_t)stream, out, hdr, L, D);
     FD_CHECK_LAUNCH("k_header_pull");

@@ -391,6 +391,7 @@ extern "C" int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma,
 extern "C" int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const float* gamma,
                                         const float* beta, float* ws, int B, int HW, int C, int G,
                                         float eps, int silu, void* stream) {
+    FD_PLAN(fd_groupnorm_nhwc_ld_f16(x, ldx, y, gamma, beta, ws, B, HW, C, G, eps, silu, fd_s_));
     FD_CHECK_ARG(ldx >= C && ldx % 8 == 0 && (uintptr_t)x % 16 == 0, FD_ESHAPE,
                  "fd_groupnorm_nhwc_ld_f16: ldx=%d must be >= C=%d, a multiple of 8, x 16-byte aligned", ldx, C);
     FD_CHECK_ARG((long long)B * HW * ldx < 0x7fffffffLL, FD_ESHAPE, "fd_groupnorm_nhwc_ld_f16: tensor too large");
@@ -519,6 +520,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const half_t* __restrict__ x,
 extern "C" int fd_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta,
                                 int rows, int C, int ldx, int ldy, float eps, int out_f32,
                                 void* stream) {
+    FD_PLAN(fd_layernorm_f16(x, y, gamma, beta, rows, C, ldx, ldy, eps, out_f32, fd_s_));
     FD_CHECK_ARG(x && y && gamma && beta && rows > 0 && C > 0, FD_EINVAL, "fd_layernorm_f16: args");
     FD_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && C <= 2048, FD_ESHAPE,
                  "fd_layernorm_f16: C=%d must be a multiple of 8 and <= 2048", C);
@@ -542,6 +544,7 @@ extern "C" int fd_layernorm_f16(const void* x, void* y, const float* gamma, cons
 }
 
 extern "C" int fd_ln_row_stats_f16(const void* x, float* stats, int rows, int C, int ldx, float eps, void* stream) {
+    FD_PLAN(fd_ln_row_stats_f16(x, stats, rows, C, ldx, eps, fd_s_));
     FD_CHECK_ARG(x && stats && rows > 0 && C > 0, FD_EINVAL, "fd_ln_row_stats_f16: args");
     FD_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && C <= 2048, FD_ESHAPE,
                  "fd_ln_row_stats_f16: C=%d must be a multiple of 8 and <= 2048", C);
@@ -604,6 +607,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(half_t* __restrict__ x, in
 }
 
 extern "C" int fd_softmax_rows_f16(void* x, int rows, int N, int ld, float scale, void* stream) {
+    FD_PLAN(fd_softmax_rows_f16(x, rows, N, ld, scale, fd_s_));
     FD_CHECK_ARG(x && rows > 0 && N > 0, FD_EINVAL, "fd_softmax_rows_f16: args");
     FD_CHECK_ARG(N % 8 == 0 && ld % 8 == 0, FD_ESHAPE, "fd_softmax_rows_f16: N, ld %% 8");
     hipLaunchKernelGGL(k_softmax_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, (half_t*)x, N,

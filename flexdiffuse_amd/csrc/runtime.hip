@@ -154,3 +154,68 @@ extern "C" int fd_prof_collect(int family, double* total_ms, double* total_work,
     if (launches) *launches = n;
     return FD_OK;
 }
+
+// ---- launch plan ------------------------------------------------------------------------------
+// The UNet forward of the denoising loop is the same ~430 launches with the same arguments at every
+// step (only the contents of the latent and timestep buffers change).  A plan records those
+// launches once -- each entry point appends a by-value copy of its own call while the calling
+// thread records -- and fd_plan_replay issues them again as ordinary eager launches on the given
+// stream: same kernels, same order, same tile choices, none of the per-op host work of the Python
+// front (tensor allocation, descriptor packing, ctypes marshalling).  Unlike a captured HIP graph
+// the device sees exactly the eager launch stream.  The caller keeps every recorded address alive
+// and unchanged (flexdiffuse_amd/pipeline/flex.py records inside a private torch memory pool).
+struct fd_plan {
+    std::vector<std::function<int(void*)>> ops;
+    bool recording = false;
+};
+static thread_local fd_plan* g_rec = nullptr;
+
+bool fd_plan_recording() { return g_rec != nullptr; }
+void fd_plan_push(std::function<int(void*)> op) {
+    if (g_rec) g_rec->ops.push_back(std::move(op));
+}
+
+extern "C" int fd_plan_create(fd_plan** out) {
+    FD_CHECK_ARG(out, FD_EINVAL, "fd_plan_create: null result pointer");
+    *out = new fd_plan();
+    return FD_OK;
+}
+
+extern "C" int fd_plan_destroy(fd_plan* plan) {
+    if (plan && g_rec == plan) g_rec = nullptr;
+    delete plan;
+    return FD_OK;
+}
+
+extern "C" int fd_plan_record_begin(fd_plan* plan) {
+    FD_CHECK_ARG(plan, FD_EINVAL, "fd_plan_record_begin: null plan");
+    FD_CHECK_ARG(g_rec == nullptr, FD_EINVAL, "fd_plan_record_begin: this thread is already recording");
+    plan->ops.clear();
+    plan->recording = true;
+    g_rec = plan;
+    return FD_OK;
+}
+
+extern "C" int fd_plan_record_end(fd_plan* plan) {
+    FD_CHECK_ARG(plan && g_rec == plan, FD_EINVAL, "fd_plan_record_end: plan is not the one being recorded");
+    plan->recording = false;
+    g_rec = nullptr;
+    return FD_OK;
+}
+
+extern "C" int fd_plan_size(const fd_plan* plan, int* launches) {
+    FD_CHECK_ARG(plan && launches, FD_EINVAL, "fd_plan_size: null argument");
+    *launches = (int)plan->ops.size();
+    return FD_OK;
+}
+
+extern "C" int fd_plan_replay(const fd_plan* plan, void* stream) {
+    FD_CHECK_ARG(plan, FD_EINVAL, "fd_plan_replay: null plan");
+    FD_CHECK_ARG(!plan->recording && g_rec == nullptr, FD_EINVAL,
+                 "fd_plan_replay: a plan cannot be replayed while this thread records");
+    for (const auto& op : plan->ops) {
+        const int rc = op(stream);
+        if (rc != FD_OK) return rc;     // the failing entry point has set the error string
+    }
+    return FD_OK;
+}

@@ -60,13 +60,20 @@ _SIGNATURES = {
     'fd_axpby_f32': (c_int, [P, P, P, c_int64, c_float, c_float, c_int, P]),
     'fd_embed_tokens_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'fd_vit_assemble_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
-    'fd_timestep_embedding_f16': (c_int, [P, P, c_int, c_int, P]),
+    'fd_timestep_embedding_f16': (c_int, [P, c_int, P, c_int, c_int, P]),
+    'fd_copy2d_f16': (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
+    'fd_plan_create': (c_int, [P]),
+    'fd_plan_destroy': (c_int, [P]),
+    'fd_plan_record_begin': (c_int, [P]),
+    'fd_plan_record_end': (c_int, [P]),
+    'fd_plan_size': (c_int, [P, P]),
+    'fd_plan_replay': (c_int, [P, P]),
     'fd_region_blend_f32': (c_int, [P, P] + [c_int] * 7 + [c_float, P]),
     'fd_cast_f32_to_f16': (c_int, [P, P, c_int64, P]),
     'fd_cast_f16_to_f32': (c_int, [P, P, c_int64, P]),
 }
 
-ABI_VERSION = 5   # FD_ABI_VERSION in include/flexdiffuse_hip.h
+ABI_VERSION = 6   # FD_ABI_VERSION in include/flexdiffuse_hip.h
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -140,6 +147,47 @@ def device_info(device: int = 0) -> dict:
          arch, 64)
     return {'cu_count': cu.value, 'clock_khz': khz.value, 'hbm_bytes': mem.value,
             'arch': arch.value.decode()}
+
+
+class Plan():
+    '''Launch plan (include/flexdiffuse_hip.h fd_plan_*): `with plan.record(): ...` runs the enclosed
+    C-ABI calls AND records them; `plan.replay()` issues them again on the current stream without
+    the per-op host work.  Every device address used inside must stay alive and unchanged (record
+    inside a private torch memory pool and keep the pool), and nothing inside may be a torch
+    kernel -- only library launches are recorded.'''
+
+    def __init__(self):
+        h = c_void_p()
+        call('fd_plan_create', ctypes.byref(h))
+        self._h = h
+        self._replay = lib().fd_plan_replay
+
+    def record(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            call('fd_plan_record_begin', self._h)
+            try:
+                yield self
+            finally:
+                call('fd_plan_record_end', self._h)
+        return cm()
+
+    def replay(self, on_stream: Optional[c_void_p] = None):
+        rc = self._replay(self._h, stream() if on_stream is None else on_stream)
+        if rc != FD_OK:
+            check(rc, 'fd_plan_replay')
+
+    def __len__(self):
+        n = c_int(0)
+        call('fd_plan_size', self._h, ctypes.byref(n))
+        return n.value
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h is not None and _lib is not None:
+            _lib.fd_plan_destroy(h)
 
 
 _prof_on = False

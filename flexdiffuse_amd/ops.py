@@ -410,6 +410,32 @@ def nhwc_to_nchw(x: torch.Tensor, B: int, C: int, H: int, W: int, a: float = 1.0
     return out
 
 
+def copy_rows(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    '''dst[r][:] = src[r][:] for fp16 matrices with arbitrary row strides (a library launch, so a
+    launch plan records it -- torch's copy_ would not be replayed).'''
+    assert dst.shape == src.shape and dst.dim() == 2 and dst.dtype == src.dtype == torch.float16
+    assert dst.stride(1) == 1 and src.stride(1) == 1
+    hip.call('fd_copy2d_f16', src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), src.shape[0],
+             src.shape[1], hip.stream())
+    return dst
+
+
+def contiguous_rows(x: torch.Tensor) -> torch.Tensor:
+    '''x itself when its rows are dense, else a dense copy made by a library launch.'''
+    if x.is_contiguous():
+        return x
+    return copy_rows(_empty(tuple(x.shape), torch.float16, x), x)
+
+
+def repeat_rows(x: torch.Tensor, rep: int) -> torch.Tensor:
+    '''fp16 [rows][C] -> [rep*rows][C]: the CFG fan-out of the shared UNet prefix.'''
+    rows, C = x.shape
+    out = _empty((rep * rows, C), torch.float16, x)
+    for r in range(rep):
+        copy_rows(out[r * rows:(r + 1) * rows], x)
+    return out
+
+
 def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     M = a.shape[0]
     out = _empty((M, a.shape[1] + b.shape[1]), torch.float16, a)

@@ -6,7 +6,11 @@ and ValueError, driving the gfx950 kernels.
 Device loop: for `SimpleGuide` + DDIM the whole step is  UNet(NHWC fp16, CFG batch built
 inside the layout kernel) -> fused CFG + DDIM update on the fp32 latents  with no host
 round trip; any other guide object goes through the reference protocol
-(`guide.noise_pred` + `scheduler.step`) unchanged.
+(`guide.noise_pred` + `scheduler.step`) unchanged.  The UNet forward of the fused loop is
+replayed from a LAUNCH PLAN (`use_plan`, default): its ~430 C-ABI launches are recorded once
+per (shape, context) and re-issued each step by one library call -- the same eager launches
+in the same order, without the Python front's per-op work, so the host stays far ahead of
+the device whatever the host CPU (8 ranks on one node share its cores).
 
 Deliberate differences: E6 initial noise is drawn on the generator's own
 device -- pass a CPU generator for results independent of the GPU count; E8 `init_image`
@@ -72,6 +76,10 @@ class FlexPipeline():
         self.use_graph = False
         self._graphs = {}
         self._lat_bufs = {}
+        # default: replay the UNet forward of the fused loop from its recorded launch plan
+        # (hip.Plan): identical kernels / order / results to the eager front, ~1/5 of its host time
+        self.use_plan = True
+        self._plans = {}
 
     @classmethod
     def from_pretrained(cls, *a, **k):
@@ -117,6 +125,8 @@ class FlexPipeline():
     def _unet_eps(self, latents: torch.Tensor, t: int, ctx: torch.Tensor, rep: int) -> torch.Tensor:
         '''UNet noise prediction (NHWC fp32) for the fused loop; graph-replayed when enabled.
         `latents` must be the loop's persistent buffer (updated in place by the DDIM kernel).'''
+        if self.use_plan and not self.use_graph:
+            return self._unet_eps_plan(latents, t, ctx, rep)
         if not self.use_graph or hip.prof_is_on():   # event timing needs eager launches
             return self.unet.forward_nhwc(latents, t, ctx, rep=rep)
         self.unet.set_context(ctx)               # eager, in place: the graph reads these buffers
@@ -145,6 +155,52 @@ class FlexPipeline():
         t_static.fill_(float(t))
         graph.replay()
         return eps
+
+    def _unet_eps_plan(self, latents: torch.Tensor, t: int, ctx: torch.Tensor, rep: int) -> torch.Tensor:
+        '''The UNet forward through its launch plan.  `latents` is the loop's persistent buffer; the
+        timestep lives in a one-element device tensor refreshed before every replay; the context's
+        K / V^T are (re)projected eagerly, in place, before the replay.  The recording run executes
+        inside a private torch memory pool that the plan entry keeps alive, so every intermediate
+        address the recorded launches use stays reserved for them.'''
+        self.unet.set_context(ctx)
+        key = (latents.data_ptr(), tuple(latents.shape), rep, tuple(ctx.shape),
+               getattr(self.unet, 'ctx_generation', 0), hip.stream().value)
+        entry = self._plans.get(key)
+        if entry is None:
+            self._plans = {}                     # one plan at a time (its pool holds the activations)
+            t_dev = torch.zeros((1,), dtype=torch.float32, device=latents.device)
+            t_dev.fill_(float(t))
+            # first call eager: one-time setup inside the launchers, scratch buffers of ops.py
+            self.unet.forward_nhwc(latents, t_dev, ctx, rep=rep)
+            if self.unet.ctx_generation != key[4]:
+                key = key[:4] + (self.unet.ctx_generation,) + key[5:]
+            pool = torch.cuda.MemPool()
+            plan = hip.Plan()
+            with torch.cuda.use_mem_pool(pool, device=latents.device), plan.record():
+                eps = self.unet.forward_nhwc(latents, t_dev, ctx, rep=rep)
+            self._plans = {key: (plan, t_dev, eps, pool, len(plan))}
+            return eps                           # the recording run also executed
+        plan, t_dev, eps = entry[:3]
+        t_dev.fill_(float(t))
+        plan.replay()
+        return eps
+
+    def plan_launches(self):
+        '''Recorded launches of the current plan (None before the first fused step).'''
+        for e in self._plans.values():
+            return e[4]
+        return None
+
+    def loop_latents(self, latents: torch.Tensor) -> torch.Tensor:
+        '''The persistent per-shape latent buffer of the fused loop, filled with `latents` (a captured
+        graph / recorded plan reads this address every step).'''
+        latents = latents.to(self.device, torch.float32)
+        buf = self._lat_bufs.get(tuple(latents.shape))
+        if buf is None:
+            buf = torch.empty_like(latents)
+            self._lat_bufs = {tuple(latents.shape): buf}
+        buf.copy_(latents)
+        return buf
 
     def _randn(self, shape, generator):
         gdev = getattr(generator, 'device', torch.device('cpu')) if generator is not None \
@@ -209,14 +265,9 @@ class FlexPipeline():
                  and isinstance(self.scheduler, DDIMScheduler) and not eta
                  and hasattr(self.unet, 'forward_nhwc'))
         B, C, H, W = latents.shape
-        if fused and self.use_graph and not debug:
-            # persistent latent buffer: the captured UNet graph reads this address every step
-            buf = self._lat_bufs.get(tuple(latents.shape))
-            if buf is None:
-                buf = torch.empty_like(latents)
-                self._lat_bufs = {tuple(latents.shape): buf}
-            buf.copy_(latents)
-            latents = buf
+        if fused and (self.use_graph or self.use_plan) and not debug:
+            # persistent latent buffer: the captured UNet graph / recorded plan reads this address
+            latents = self.loop_latents(latents)
         is_lms = isinstance(self.scheduler, LMSDiscreteScheduler)
         # The host only has to stay ahead of the device queue.  A generation-2 collection of the
         # cyclic GC walks every tracked object of the process (~175 k with the SD1.5 weights:

@@ -276,7 +276,7 @@ class UNet2DConditionModel():
             for r in range(rep):
                 ops.attention(q2, kc[r * B * L:(r + 1) * B * L], vtc[r * B:(r + 1) * B], B, a.heads,
                               HW, L, d, q_prescaled=a.q_pre, out=o[r * B * HW:(r + 1) * B * HW])
-            h, xt, B = h.repeat(rep, 1), xt.repeat(rep, 1), rep * B
+            h, xt, B = ops.repeat_rows(h, rep), ops.repeat_rows(xt, rep), rep * B
         st = mkst(B * HW)
         h = ops.gemm(o, a.o2, residual=h, ln_stats_out=st)
         if a.ln_fold:
@@ -291,12 +291,18 @@ class UNet2DConditionModel():
         '''[B][sum Cout] fp32: every ResBlock's Linear(SiLU(time_embedding(t))).'''
         dev = self.device
         if isinstance(timestep, torch.Tensor):
-            t = timestep.to(dev, torch.float32).reshape(-1).expand(B).contiguous()
+            # a one-element device tensor is read by every sample (stride 0): the denoising loop
+            # refreshes that scalar between replays of the forward's launch plan
+            t = timestep.to(dev, torch.float32).reshape(-1)
+            if t.numel() not in (1, B):
+                raise ValueError(f'timestep tensor has {t.numel()} elements for a batch of {B}')
+            t = t.contiguous()
         else:
-            t = torch.full((B,), float(timestep), dtype=torch.float32, device=dev)
+            t = torch.full((1,), float(timestep), dtype=torch.float32, device=dev)
         dim = self.cfg.block_out_channels[0]
         e = torch.empty((B, dim), dtype=torch.float16, device=dev)
-        hip.call('fd_timestep_embedding_f16', t.data_ptr(), e.data_ptr(), B, dim, hip.stream())
+        hip.call('fd_timestep_embedding_f16', t.data_ptr(), 0 if t.numel() == 1 else 1, e.data_ptr(), B, dim,
+                 hip.stream())
         e = ops.gemm(e, self.t1, act=ops.ACT_SILU)
         e = ops.gemm(e, self.t2, act=ops.ACT_SILU)   # only SiLU(emb) is ever consumed
         return ops.gemm(e, self.temb_all, out_f32=True)
@@ -343,10 +349,10 @@ class UNet2DConditionModel():
         if fan > 1:
             h = ops.conv2d(x, self.conv_in)
             if view is None:
-                push(Act(h.t.repeat(fan, 1), Be, h.H, h.W), None, None)
+                push(Act(ops.repeat_rows(h.t, fan), Be, h.H, h.W), None, None)
             else:
                 for f in range(fan):
-                    view[f * x.B * HW:(f + 1) * x.B * HW].copy_(h.t)
+                    ops.copy_rows(view[f * x.B * HW:(f + 1) * x.B * HW], h.t)
                 push(Act(view, Be, h.H, h.W), buf, ch)
         else:
             h = push(ops.conv2d(x, self.conv_in, out=view), buf, ch)
@@ -360,10 +366,10 @@ class UNet2DConditionModel():
                 elif fan > 1:
                     h = self._res(r, h, temb[:h.B])
                     if view is None:
-                        h = Act(h.t.repeat(fan, 1), Be, h.H, h.W)
+                        h = Act(ops.repeat_rows(h.t, fan), Be, h.H, h.W)
                     else:
                         for f in range(fan):
-                            view[f * h.B * h.HW:(f + 1) * h.B * h.HW].copy_(h.t)
+                            ops.copy_rows(view[f * h.B * h.HW:(f + 1) * h.B * h.HW], h.t)
                         h = Act(view, Be, h.H, h.W)
                 else:
                     h = self._res(r, h, temb[:h.B], out=view)
@@ -382,7 +388,7 @@ class UNet2DConditionModel():
                 if sbuf is not None and h.t.data_ptr() == sbuf.data_ptr() and h.C == sch:
                     h = Act(sbuf, h.B, h.H, h.W)          # both halves are already in place
                 else:
-                    h = Act(ops.concat_channels(h.t.contiguous(), s.t.contiguous()), h.B, h.H, h.W)
+                    h = Act(ops.concat_channels(ops.contiguous_rows(h.t), ops.contiguous_rows(s.t)), h.B, h.H, h.W)
                 # where the result of this sub-block goes: the next concat's left half, unless an
                 # upsample conv (contiguous input) follows
                 last = j == n - 1

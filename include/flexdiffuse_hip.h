@@ -32,7 +32,7 @@ extern "C" {
 #define FD_ESHAPE (-2) /* unsupported shape / alignment */
 #define FD_EHIP (-3)   /* HIP runtime error */
 
-#define FD_ABI_VERSION 5
+#define FD_ABI_VERSION 6
 
 int fd_abi_version(void);
 const char* fd_last_error(void);
@@ -57,6 +57,24 @@ int fd_prof_collect(int family, double* total_ms, double* total_work, int64_t* l
 /* Mean elapsed ms of an EMPTY event bracket (`pairs` back-to-back record pairs on `stream`);
  * subtract it per sampled launch to turn bracket time into kernel time. Host pointer. */
 int fd_prof_calibrate(int pairs, double* ms_per_empty_pair, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Launch plan.  The denoising loop (reference pipeline/flex.py:262-287) calls the UNet with the
+ * same shapes at every step: the ~430 launches of a forward differ only in the CONTENTS of the
+ * latent and timestep buffers.  While a thread records (fd_plan_record_begin .. _end) every launch
+ * entry point of this library, besides launching, appends a by-value copy of its own call to the
+ * plan; fd_plan_replay issues the recorded calls again on `stream` as ordinary eager launches
+ * (same kernels, order and tile choices; none of the host front's per-op work).  The caller keeps
+ * every recorded device address alive and unchanged and refreshes the input buffers between
+ * replays.  Recording is per thread; a plan may be replayed from any ONE thread at a time.
+ * ---------------------------------------------------------------------------------- */
+typedef struct fd_plan fd_plan;
+int fd_plan_create(fd_plan** out);
+int fd_plan_destroy(fd_plan* plan);
+int fd_plan_record_begin(fd_plan* plan); /* clears the plan; the calling thread records */
+int fd_plan_record_end(fd_plan* plan);
+int fd_plan_size(const fd_plan* plan, int* launches); /* recorded entry-point calls */
+int fd_plan_replay(const fd_plan* plan, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Guidance: CLIP image<->text token alignment and tween  (reference guidance.py)
@@ -248,8 +266,13 @@ int fd_embed_tokens_f16(const int64_t* ids, const void* tok_emb, const void* pos
                         int B, int L, int D, int vocab, void* stream);
 int fd_vit_assemble_f16(const void* patches, const void* cls, const void* pos, void* out, int B,
                         int T, int D, void* stream);
-/* diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0): t [B] fp32 -> fp16 [B][dim]. */
-int fd_timestep_embedding_f16(const float* t, void* out, int B, int dim, void* stream);
+/* diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0): t fp32 -> fp16 [B][dim]; sample b reads
+ * t[b * t_stride], t_stride 1 (one timestep per sample) or 0 (one device scalar for the batch: the
+ * denoising loop's timestep, refreshed between replays of a launch plan). */
+int fd_timestep_embedding_f16(const float* t, int t_stride, void* out, int B, int dim, void* stream);
+/* dst[r][0..cols) = src[r][0..cols) for fp16 matrices with row strides lds / ldd (elements);
+ * cols, lds, ldd multiples of 8, pointers 16-byte aligned.  The CFG fan-out copies of the UNet. */
+int fd_copy2d_f16(const void* src, int lds, void* dst, int ldd, int64_t rows, int cols, void* stream);
 /* CompositeGuide region blend (reference composition/guide.py:86-98), NCHW fp32 [C][H][W]:
  * dst[:, oy:oy+sh, ox:ox+sw] += blend * (src - dst) on the same box.  oy, ox >= 0: the host
  * resolves Python's slice semantics (negative starts count from the end of the axis) first;

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
 def test_ctypes_table_matches_header():
     from flexdiffuse_amd import hip
     assert sorted(hip.declared_symbols()) == declared_in_header()
-    assert hip.lib().fd_abi_version() == hip.ABI_VERSION == 5
+    assert hip.lib().fd_abi_version() == hip.ABI_VERSION == 6
 
 
 def test_struct_layouts_match_header():
@@ -58,6 +58,31 @@ def test_argument_errors_without_gpu():
     with pytest.raises(ValueError):
         hip.call('fd_guidance_map', None, None, None, None, None, 1, 0, 10, 77, 48, 1, 1, None)
     assert b'multiple of 32' in hip.lib().fd_last_error()
+
+
+def test_launch_plan_lifecycle_without_gpu():
+    '''fd_plan_* host logic (no launches): a plan records only between begin / end on the calling
+    thread, refuses a second recorder and a replay while recording, and an empty plan replays.'''
+    from flexdiffuse_amd import hip
+    plan = hip.Plan()
+    assert len(plan) == 0
+    null = ctypes.c_void_p(0)
+    plan.replay(null)                               # empty plan: nothing to launch
+    with plan.record():
+        with pytest.raises(ValueError, match='already recording'):
+            with hip.Plan().record():
+                pass
+        with pytest.raises(ValueError, match='while this thread records'):
+            plan.replay(null)
+        # a call that fails its argument check is still recorded by value: replay reports it too
+        with pytest.raises(ValueError):
+            hip.call('fd_guidance_map', None, None, None, None, None, 1, 0, 10, 77, 48, 1, 1, None)
+    assert len(plan) == 1
+    with pytest.raises(ValueError, match='multiple of 32'):
+        plan.replay(null)
+    with plan.record():                             # begin clears the plan
+        pass
+    assert len(plan) == 0
 
 
 def test_no_cpu_fallback():

@@ -113,14 +113,61 @@ def test_single_process_is_identity():
     assert fdist.shard_range(2, 8, 8) == slice(16, 24)
 
 
+def test_bench_launcher_eight_gloo_ranks_plumbing():
+    '''`bench.py --gpus 8` from a parent that imports neither torch nor HIP: eight fresh children
+    rendezvous on 127.0.0.1 over gloo, take their shards of the host-drawn global batch, gather and
+    max-reduce the clock; rank 0 reports n_gpus 8.  FD_BENCH_PLUMBING=1 leaves the GPU hot path out
+    (there is no GPU here and the product has no CPU fallback) -- the line says it is not a
+    benchmark.  The same launcher drives the real 8-GPU run.'''
+    import json
+    bench = os.path.join(ROOT, 'bench.py')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(FD_BENCH_PLUMBING='1', OMP_NUM_THREADS='1')
+    r = subprocess.run([sys.executable, bench, '--gpus', '8', '--preset', 'mini', '--size', '64', '--batch', '2'],
+                       env=env, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and line['gather_equals_global_batch'] and line['backend'] == 'gloo'
+    assert line['rccl_ranks'] == 0 and 'NOT a benchmark' in line['metric']
+
+
+def test_bench_parent_never_loads_torch():
+    '''The parent of an N-rank run starts its children with the standard library only: importing
+    bench and calling launch_ranks must not pull torch (and with it the HIP runtime) into the
+    process.'''
+    code = ('import sys; sys.argv = ["bench.py", "--gpus", "2"]; sys.path.insert(0, %r); import bench; '
+            'import os; os.environ["FD_BENCH_PLUMBING"] = "1"; rc = bench.launch_ranks(2); '
+            'assert "torch" not in sys.modules and "numpy" not in sys.modules, "parent loaded torch"; '
+            'sys.exit(rc)') % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, '-c', code], env=dict(env, OMP_NUM_THREADS='1'), capture_output=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b'"n_gpus": 2' in r.stdout
+
+
+def test_bench_dead_rank_takes_the_others_down():
+    '''A rank that dies before the rendezvous must not leave its peers waiting in it: the launcher
+    terminates the rest and reports the failure (here: no device visible in any child).'''
+    bench = os.path.join(ROOT, 'bench.py')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    if torch.cuda.device_count() == 0:
+        r = subprocess.run([sys.executable, bench, '--gpus', '2', '--preset', 'mini'], env=env,
+                           capture_output=True, timeout=300)
+        assert r.returncode != 0 and b'device(s) visible' in r.stderr and not r.stdout.strip()
+
+
 def test_bench_refuses_rank_count_it_cannot_start():
     '''`bench.py --gpus N` must never fall back to one GPU silently: with fewer than N visible
     devices (none in the CPU container) it exits non-zero, and under a torchrun environment a
     WORLD_SIZE different from --gpus is an error too.'''
     bench = os.path.join(ROOT, 'bench.py')
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
-    if torch.cuda.device_count() < 64:
-        r = subprocess.run([sys.executable, bench, '--gpus', '64'], env=env, capture_output=True, timeout=300)
+    if torch.cuda.device_count() < 3:
+        # every child checks its own device before the rendezvous and exits 2
+        r = subprocess.run([sys.executable, bench, '--gpus', '3'], env=env, capture_output=True, timeout=300)
         assert r.returncode != 0 and b'device(s) visible' in r.stderr and not r.stdout.strip()
     r = subprocess.run([sys.executable, bench, '--gpus', '1'], env=dict(env, WORLD_SIZE='2', RANK='0'),
                        capture_output=True, timeout=300)

@@ -71,17 +71,34 @@ def test_bench_launches_two_ranks():
     collective runs over gloo (RCCL refuses two ranks on one device); what is under test is the
     launcher, the sharding and the gather of 2 x batch samples.'''
     line = _bench(['--gpus', '2'] + MINI, FD_BENCH_SHARE_GPU='1', FD_DIST_BACKEND='gloo')
-    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2
+    assert line['n_gpus'] == 2
+    # rccl_ranks counts ranks of an RCCL ("nccl") process group only: this run's collective went
+    # over gloo, so RCCL saw no rank and the line must say so
+    assert line['rccl_ranks'] == 0 and line['dist_backend'] == 'gloo'
     assert line['config']['images_per_step'] == 4 and line['scaling'] == 'weak'
     assert line['all_gather']['bytes_per_rank'] > 0 and line['value'] > 0
+
+
+def test_bench_launches_eight_ranks():
+    '''The 8-rank shape of the driver's scaling run, on the box's ONE GPU: `bench.py --gpus 8`
+    starts eight fresh children from a parent that never touches the GPU; each rank builds its own
+    model, runs its shard through its own launch plan and takes part in the gather (gloo: RCCL
+    refuses eight ranks on one device).  Under test: eight concurrent host loops, the launcher, the
+    sharding and the gather of 8 x batch samples.'''
+    line = _bench(['--gpus', '8'] + MINI, FD_BENCH_SHARE_GPU='1', FD_DIST_BACKEND='gloo')
+    assert line['n_gpus'] == 8 and line['rccl_ranks'] == 0 and line['dist_backend'] == 'gloo'
+    assert line['config']['images_per_step'] == 16 and line['value'] > 0
+    assert line['host_margin']['launch'] == 'plan' and line['host_margin']['launches_per_forward'] > 50
 
 
 def test_bench_single_rank_rccl_line():
     '''N = 1 through the RCCL path (FD_FORCE_DIST=1): same line shape, rccl_ranks 1, and the
     roofline / all_gather objects are present and self-consistent.'''
     line = _bench(['--gpus', '1'] + MINI, FD_FORCE_DIST='1', MASTER_PORT='29533')
-    assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1
+    assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1 and line['dist_backend'] == 'nccl'
     assert line['all_gather']['backend'].startswith('RCCL') and line['all_gather']['bytes_per_rank'] > 0
+    hm = line['host_margin']
+    assert hm['launch'] == 'plan' and 0 < hm['host_ms_per_forward'] and hm['launches_per_forward'] > 50
     rf = line['roofline']
     assert rf['bound'] == 'mfma' and rf['peak'] == 2516.6 and 0 < rf['frac'] < 1
     assert rf['families_fit_in_step'] and 0 < rf['frac_best_kernel'] < 1

@@ -478,6 +478,63 @@ def test_hip_graph_replay_matches_eager(mini, dev):
         pipe.use_graph = False
 
 
+def test_launch_plan_replay_matches_eager_front(mini, dev):
+    """Default launch mode: the UNet forward of the fused loop is replayed from its recorded launch
+    plan (hip.Plan / fd_plan_*).  Bit-identical latents to the eager Python front, also when prompts,
+    noise and step count change between calls (every input of the recorded launches lives in a
+    buffer that is refreshed: a torch op missed by the recorder would replay stale data)."""
+    from flexdiffuse_amd import SimpleGuide
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    sds, pipe, clip, tok, _ = mini
+    enc = CLIPEncoder(clip, tok)
+
+    def run(prompts, seed, steps):
+        g = SimpleGuide(enc, pipe.unet, 8.0, steps, enc.prompt(prompts))
+        pipe(guide=g, init_size=(64, 64), generator=torch.Generator('cpu').manual_seed(seed), output_type='np')
+        return pipe.last_latents.clone()
+    cases = [(['a photo of a turtle', 'zeus, oil painting'], 1337, 3),
+             (['a deer in a forest', 'neon city at night'], 7, 4),
+             (['a photo of a turtle', 'zeus, oil painting'], 1337, 3)]
+    try:
+        pipe.use_plan = False
+        eager = [run(*c) for c in cases]
+        assert pipe.plan_launches() is None or True
+        pipe.use_plan, pipe._plans = True, {}
+        plan = [run(*c) for c in cases]
+        n = pipe.plan_launches()
+    finally:
+        pipe.use_plan = True
+    assert n is not None and n > 50, n
+    for e, p in zip(eager, plan):
+        assert torch.equal(e, p)
+    assert not torch.equal(plan[0], plan[1]) and torch.equal(plan[0], plan[2])
+
+
+def test_launch_plan_full_size_unet_step(sd15, dev):
+    """The recorded plan of the full-size SD1.5 UNet (CFG batch 2 x 2 at 64x64 latents: shared CFG
+    prefix, in-place skip concats, LayerNorm-fold statistics, split-K deep levels) replays
+    bit-identically to the eager front for new latents / timestep / context."""
+    sds, pipe, clip, tok, _ = sd15
+    g = torch.Generator().manual_seed(5)
+    ctxs = [torch.randn((4, 77, 768), generator=g).half().to(dev) for _ in range(2)]
+    lats = [torch.randn((2, 4, 64, 64), generator=g) for _ in range(2)]
+    try:
+        got, want = [], []
+        for use in (False, True):
+            pipe.use_plan, pipe._plans = use, {}
+            for i, t in enumerate((801, 401, 21)):
+                lat = pipe.loop_latents(lats[i % 2])
+                eps = pipe._unet_eps(lat, t, ctxs[i % 2], 2)
+                (got if use else want).append(eps.clone())
+        n = pipe.plan_launches()
+    finally:
+        pipe.use_plan = True
+    assert n > 300, n
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert not torch.equal(got[0], got[1])
+
+
 def _eps_ref(mini):
     from oracle import clip_ref, pipeline_ref
     sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = mini
