@@ -1,0 +1,408 @@
+// Fused cross-attention front half for gfx950: LayerNorm-fold q projection + softmax(Q K^T) V over
+// the SHORT, step-invariant text context, in ONE launch.
+//
+// Replaces, inside `unet(...)` (reference pipeline/guide.py:56-58; diffusers' BasicTransformerBlock
+// attn2), the q-projection GEMM launch and the cross-attention launch at the 64x64 level
+// (C = 320 = 8 heads x 40): the query matrix (42 MB at CFG batch 16) is no longer written to and
+// re-read from HBM.  The hidden states are read once, the attention output is written once.
+//
+// Structure: the 256x320 / 16-wave tile of gemm.hip (64x80 wave tiles, LDS-DMA K loop, LayerNorm
+// fold) computes Q for 256 rows x all 8 heads; wave column wn owns the 80 columns of head pair
+// (2 wn, 2 wn + 1).  The accumulators -- rounded to fp16 exactly like the q tensor the unfused path
+// stores -- ARE the B operands of S^T = K Q^T (a lane owns one query column): no exchange.  The
+// context's K and V^T (77 keys) are step-invariant, so they are packed ONCE per context into the
+// per-lane MFMA fragment order ("images", fd_xattn_pack_kv_f16); the kernel DMAs the 60 KB K image
+// into the K-loop stage that is already dead during the last K-tile and the 60 KB V^T image into
+// the other stage right after the loop, and reads fragments lane-linearly (conflict-free).
+// Softmax over all 77 keys happens in one piece (exact row max, no online rescale); the
+// denominator rides through the PV MFMA on a ones-row of the V^T image (row 40 of 48).
+//
+// Head dim 40 on 16-wide fragments: the wave's fragment 2 (columns 32..47) holds head A's channels
+// 32..39 and head B's channels 0..7.  Instead of padding, the K image of each head carries zeros
+// at the other head's k-slots of that fragment, so the contraction picks exactly its own channels;
+// the 8-channel remainder uses v_mfma_f32_16x16x16_f16 (half the fragment bytes of the K = 32 form).
+#include <stdlib.h>
+
+#include "common.h"
+
+#define XBK 64
+typedef unsigned int xu32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int xu32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) float* xlds_cfloat;
+typedef const __attribute__((address_space(3))) floatx4* xlds_cf4;
+
+struct XattnArgs {
+    const half_t* A;        // hidden states [M][lda], un-normalised
+    const half_t* W;        // [320][ldw] gain-folded, pre-scaled q weights
+    const float* bias;      // [320] folded bias
+    const float* colsum;    // [320] column sums of the folded weights
+    const float* ln_stats;  // [M][2] (rstd, -mean rstd)
+    const char* kimg;       // [samples][XA_KIMG] K images
+    const char* vimg;       // [samples][XA_VIMG] V^T images
+    half_t* O;              // [nrep * M][ldo]
+    int M, lda, ldw, ldo;
+    int rows_per_sample, nrep, samples_per_rep, n_keys;
+};
+
+constexpr int XA_HEADS = 8, XA_D = 40, XA_C = 320;
+constexpr int XA_KB = 5;                                   // 16-key blocks (80 >= 77 keys)
+constexpr int XA_KHEAD = XA_KB * 1536;                     // per head: 5 x (1024 B k32 + 512 B k16)
+constexpr int XA_KIMG = XA_HEADS * XA_KHEAD;               // 61,440 B
+constexpr int XA_VHEAD = 3 * 2560;                         // per head: 3 d-tiles x (1024 + 1024 + 512 B)
+constexpr int XA_VIMG = XA_HEADS * XA_VHEAD;               // 61,440 B
+
+// ---- image packing (once per context) ---------------------------------------------------------
+// K image, head h, key block kb: [k32: lane (fr, fq) -> 8 halfs][k16: lane -> 4 halfs], key = kb*16 + fr.
+//   even head (A of its pair): k32 = {ch fq*4 + 0..3, ch 16 + fq*4 + 0..3}; k16 = ch 32 + fq*4 + 0..3 for fq < 2, else 0
+//   odd head  (B of its pair): k32 = {ch 8 + fq*4 + 0..3, ch 24 + fq*4 + 0..3}; k16 = ch (fq-2)*4 + 0..3 for fq >= 2, else 0
+// V^T image, head h, d-tile dt (row d = dt*16 + fr; d == 40: ones, 41..47: zero), key group kg:
+//   kg 0 / 1 (k32): {key (2kg)*16 + fq*4 + 0..3, key (2kg+1)*16 + fq*4 + 0..3};  kg 2 (k16): key 64 + fq*4 + 0..3
+// Keys >= n_keys are zero everywhere (ones-row included), so padded keys add nothing.
+__global__ void k_xattn_pack(const half_t* __restrict__ K, const half_t* __restrict__ Vt, char* __restrict__ kimg,
+                             char* __restrict__ vimg, int L, int ldk, int ldvt, long long sK, long long sVt) {
+    const int b = blockIdx.y, h = blockIdx.x;
+    const half_t* Kb = K + (size_t)b * sK + h * XA_D;
+    const half_t* Vb = Vt + (size_t)b * sVt + (size_t)h * XA_D * ldvt;
+    half_t* ki = reinterpret_cast<half_t*>(kimg + (size_t)b * XA_KIMG + (size_t)h * XA_KHEAD);
+    half_t* vi = reinterpret_cast<half_t*>(vimg + (size_t)b * XA_VIMG + (size_t)h * XA_VHEAD);
+    const bool odd = h & 1;
+    for (int e = threadIdx.x; e < XA_KB * 64; e += blockDim.x) {
+        const int kb = e >> 6, lane = e & 63, fr = lane & 15, fq = lane >> 4;
+        const int key = kb * 16 + fr;
+        half_t* o32 = ki + kb * 768 + lane * 8;          // 1536 B = 768 halfs per key block
+        half_t* o16 = ki + kb * 768 + 512 + lane * 4;
+        for (int i = 0; i < 8; ++i) {
+            const int ch = (odd ? 8 : 0) + (i < 4 ? fq * 4 + i : 16 + fq * 4 + (i - 4));
+            o32[i] = key < L ? Kb[(size_t)key * ldk + ch] : (half_t)0.f;
+        }
+        for (int i = 0; i < 4; ++i) {
+            half_t v = (half_t)0.f;
+            if (key < L) {
+                if (!odd && fq < 2) v = Kb[(size_t)key * ldk + 32 + fq * 4 + i];
+                if (odd && fq >= 2) v = Kb[(size_t)key * ldk + (fq - 2) * 4 + i];
+            }
+            o16[i] = v;
+        }
+    }
+    for (int e = threadIdx.x; e < 3 * 3 * 64; e += blockDim.x) {
+        const int lane = e & 63, kg = (e >> 6) % 3, dt = e / 192, fr = lane & 15, fq = lane >> 4;
+        const int d = dt * 16 + fr;
+        half_t* o = vi + dt * 1280 + (kg == 0 ? 0 : kg == 1 ? 512 : 1024) + lane * (kg == 2 ? 4 : 8);
+        const int n = kg == 2 ? 4 : 8;
+        for (int i = 0; i < n; ++i) {
+            const int key = kg == 2 ? 64 + fq * 4 + i
+                                    : (i < 4 ? (2 * kg) * 16 + fq * 4 + i : (2 * kg + 1) * 16 + fq * 4 + (i - 4));
+            half_t v = (half_t)0.f;
+            if (key < L) {
+                if (d < XA_D) v = Vb[(size_t)d * ldvt + key];
+                else if (d == XA_D) v = (half_t)1.f;
+            }
+            o[i] = v;
+        }
+    }
+}
+
+extern "C" int fd_xattn_pack_kv_f16(const void* K, const void* Vt, void* kimg, void* vimg, int samples, int n_keys,
+                                    int heads, int head_dim, int ldk, int ldvt, int64_t k_sample_stride,
+                                    int64_t vt_sample_stride, void* stream) {
+    FD_PLAN(fd_xattn_pack_kv_f16(K, Vt, kimg, vimg, samples, n_keys, heads, head_dim, ldk, ldvt, k_sample_stride,
+                                 vt_sample_stride, fd_s_));
+    FD_CHECK_ARG(K && Vt && kimg && vimg && samples > 0, FD_EINVAL, "fd_xattn_pack_kv_f16: args");
+    FD_CHECK_ARG(heads == XA_HEADS && head_dim == XA_D && n_keys >= 1 && n_keys <= 80, FD_ESHAPE,
+                 "fd_xattn_pack_kv_f16: 8 heads x 40, at most 80 keys (got %d x %d, %d keys)", heads, head_dim, n_keys);
+    FD_CHECK_ARG(ldvt >= n_keys && ldk >= heads * head_dim, FD_ESHAPE, "fd_xattn_pack_kv_f16: leading dimensions");
+    hipLaunchKernelGGL(k_xattn_pack, dim3(XA_HEADS, samples), dim3(256), 0, (hipStream_t)stream, (const half_t*)K,
+                       (const half_t*)Vt, (char*)kimg, (char*)vimg, n_keys, ldk, ldvt, (long long)k_sample_stride,
+                       (long long)vt_sample_stride);
+    FD_CHECK_LAUNCH("k_xattn_pack");
+    return FD_OK;
+}
+
+extern "C" int64_t fd_xattn_image_bytes(int heads, int head_dim) {
+    return (heads == XA_HEADS && head_dim == XA_D) ? (int64_t)XA_KIMG : 0;   // K and V^T images have the same size
+}
+
+// ---- the fused kernel -------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes, unsigned w_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 256, BN = 320, WM = 4, WN = 4, NW = 16;
+    constexpr int WTM = 64, WTN = 80, MI = 4, NI = 5;
+    constexpr int AG = BM / 8, BG = BN / 8;            // 8-row DMA groups: 32 / 40
+    constexpr int AR = AG / NW, BR = (BG + NW - 1) / NW;   // 2 / 3 DMA instructions per wave
+    constexpr int STAGE = (BM + BN) * 128;             // 73,728 B >= one image
+    static_assert(STAGE >= XA_KIMG && STAGE >= XA_VIMG, "an image must fit one dead K-loop stage");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, w_bytes, 0x00020000);
+    float* bias_s = reinterpret_cast<float*>(smem + 2 * STAGE);   // [320] bias | [320] colsum | [256][2] row statistics
+    float* stats_s = bias_s + 2 * BN;
+    {
+        // the tile's LayerNorm row statistics ride along too: a global load in the epilogue would be waited
+        // for with vmcnt(0), i.e. together with the V^T image DMA issued just before it
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(g.ln_stats + 2 * (size_t)m0), 0, BM * 8u, 0x00020000);
+        if (wave < BM * 2 / 64)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lds_ptr)(stats_s + wave * 64), 4, (unsigned)(wave * 64 + lane) * 4u, 0, 0, 0);
+    }
+    {
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.bias, 0, XA_C * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)g.colsum, 0, XA_C * 4u, 0x00020000);
+        if (wave * 64 + lane < BN) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(bias_s + wave * 64), 4, (unsigned)(wave * 64 + lane) * 4u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsC, (lds_ptr)(bias_s + BN + wave * 64), 4, (unsigned)(wave * 64 + lane) * 4u, 0, 0, 0);
+        }
+    }
+    const int rsub = lane >> 3;
+    const int ck = (lane & 7) ^ rsub;
+    unsigned a_voff[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) a_voff[i] = (unsigned)((m0 + (i * NW + wave) * 8 + rsub) * g.lda + ck * 8) * 2u;
+    const unsigned b_voff0 = (unsigned)((wave * 8 + rsub) * g.ldw + ck * 8) * 2u;
+    const int b_group = NW * 8 * g.ldw * 2;
+    constexpr int nk = XA_C / XBK;   // 5 K-tiles
+
+#define XA_DMA_TILE(KT, BUF)                                                                     \
+    {                                                                                            \
+        char* stage = smem + (BUF) * STAGE;                                                      \
+        const int soff = (KT) * XBK * 2;                                                         \
+        _Pragma("unroll") for (int i = 0; i < AR; ++i)                                           \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(stage + (i * NW + wave) * 1024), 16, a_voff[i], soff, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < BR; ++i)                                           \
+            if (i * NW + wave < BG)                                                              \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(stage + BM * 128 + (i * NW + wave) * 1024), 16, b_voff0, soff + i * b_group, 0, 0); \
+    }
+    // an image (61,440 B = 60 x 1 KB, lane-linear) into a dead stage: chunk c by wave c % 16
+#define XA_DMA_IMAGE(RS, BUF)                                                                    \
+    {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+            if (i * NW + wave < XA_KIMG / 1024)                                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr)(smem + (BUF) * STAGE + (i * NW + wave) * 1024), 16, \
+                                                         (unsigned)lane * 16u, (i * NW + wave) * 1024, 0, 0); \
+    }
+
+    floatx4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int sample = m0 / g.rows_per_sample;   // the tile lies in one sample (rows_per_sample % 256 == 0)
+    __amdgpu_buffer_rsrc_t rsKi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.kimg + (size_t)sample * XA_KIMG), 0, XA_KIMG, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsVi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.vimg + (size_t)sample * XA_VIMG), 0, XA_VIMG, 0x00020000);
+
+    XA_DMA_TILE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int frag_a = (wm * WTM + fr) * 128, frag_b = BM * 128 + (wn * WTN + fr) * 128;
+    const int sw0 = ((0 * 4 + fq) ^ (fr & 7)) << 4, sw1 = ((1 * 4 + fq) ^ (fr & 7)) << 4;
+    int cur = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            XA_DMA_TILE(kt + 1, cur ^ 1);
+        } else {
+            XA_DMA_IMAGE(rsKi, cur ^ 1);   // the other stage is dead during the last K-tile
+        }
+        const char* st = smem + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int sw = ks ? sw1 : sw0;
+            half8 fa[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const half8*>(st + frag_a + i * 2048 + sw);
+            half8 fb[NI];
+            fb[0] = *reinterpret_cast<const half8*>(st + frag_b + sw);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                if (j + 1 < NI) fb[j + 1] = *reinterpret_cast<const half8*>(st + frag_b + (j + 1) * 2048 + sw);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    // here: every wave is past the last K-tile; stage `cur` holds the K image, stage `cur ^ 1` is dead
+    const char* sK = smem + cur * STAGE;
+    const char* sV = smem + (cur ^ 1) * STAGE;
+    XA_DMA_IMAGE(rsVi, cur ^ 1);
+
+    // ---- Q = LN-fold(acc) rounded to fp16 (exactly what the unfused q projection stores) -------
+    half4 qh[MI][NI];
+    {
+        floatx2 st[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            st[i] = *reinterpret_cast<const __attribute__((address_space(3))) floatx2*>(
+                (xlds_cfloat)stats_s + 2 * (wm * WTM + i * 16 + fr));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const floatx4 bb = *reinterpret_cast<xlds_cf4>((xlds_cfloat)bias_s + wn * WTN + j * 16 + fq * 4);
+            const floatx4 cs = *reinterpret_cast<xlds_cf4>((xlds_cfloat)bias_s + BN + wn * WTN + j * 16 + fq * 4);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    qh[i][j][r] = (half_t)fmaf(acc[i][j][r], st[i][0], fmaf(st[i][1], cs[r], bb[r]));
+        }
+    }
+
+    const int kb_last_valid = g.n_keys - 64 - fq * 4;   // key 64 + fq*4 + r is real iff r < kb_last_valid
+#pragma unroll 1
+    for (int rep = 0; rep < g.nrep; ++rep) {
+        if (rep > 0) {
+            // next replica of the context (CFG fan-out of a shared prefix): swap both images
+            __syncthreads();
+            const size_t s2 = (size_t)(rep * g.samples_per_rep + sample);
+            rsKi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.kimg + s2 * XA_KIMG), 0, XA_KIMG, 0x00020000);
+            rsVi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.vimg + s2 * XA_VIMG), 0, XA_VIMG, 0x00020000);
+            XA_DMA_IMAGE(rsKi, cur);
+            XA_DMA_IMAGE(rsVi, cur ^ 1);
+        }
+        bool v_ready = false;
+        if (rep > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            v_ready = true;
+        }
+        half_t* Ob = g.O + ((size_t)rep * g.M + m0 + wm * WTM) * g.ldo + wn * WTN;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const char* kh = sK + (wn * 2 + hh) * XA_KHEAD;
+            const char* vh = sV + (wn * 2 + hh) * XA_VHEAD;
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                // ---- S^T = K Q^T for two 16-query blocks (they share every K fragment read) ----
+                floatx4 s[2][XA_KB];
+#pragma unroll
+                for (int kb = 0; kb < XA_KB; ++kb) {
+                    const half8 k32 = *reinterpret_cast<const half8*>(kh + kb * 1536 + lane * 16);
+                    const half4 k16 = *reinterpret_cast<const half4*>(kh + kb * 1536 + 1024 + lane * 8);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int i = ip * 2 + t;
+                        const half4 qa = qh[i][hh ? 3 : 0], qb = qh[i][hh ? 4 : 1];
+                        const half8 q32 = {qa[0], qa[1], qa[2], qa[3], qb[0], qb[1], qb[2], qb[3]};
+                        floatx4 v = __builtin_amdgcn_mfma_f32_16x16x32_f16(k32, q32, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        s[t][kb] = __builtin_amdgcn_mfma_f32_16x16x16f16(k16, qh[i][2], v, 0, 0, 0);
+                    }
+                }
+                // ---- softmax over the n_keys keys (base-2 logits: the scale is folded into Wq) ----
+                half4 p[2][XA_KB];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r >= kb_last_valid) s[t][4][r] = -INFINITY;
+                    float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
+#pragma unroll
+                    for (int kb = 1; kb < XA_KB; ++kb)
+                        mx = fmaxf(mx, fmaxf(fmaxf(s[t][kb][0], s[t][kb][1]), fmaxf(s[t][kb][2], s[t][kb][3])));
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+                    for (int kb = 0; kb < XA_KB; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) p[t][kb][r] = (half_t)__builtin_amdgcn_exp2f(s[t][kb][r] - mx);
+                }
+                if (!v_ready) {   // first use of the V^T image in this launch
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    v_ready = true;
+                }
+                // ---- O^T = V^T P^T (row 40 of the image is all ones: the softmax denominator) ----
+                floatx4 o[2][3];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt) o[t][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    const half8 v0 = *reinterpret_cast<const half8*>(vh + dt * 2560 + lane * 16);
+                    const half8 v1 = *reinterpret_cast<const half8*>(vh + dt * 2560 + 1024 + lane * 16);
+                    const half4 v2 = *reinterpret_cast<const half4*>(vh + dt * 2560 + 2048 + lane * 8);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const half8 p0 = {p[t][0][0], p[t][0][1], p[t][0][2], p[t][0][3], p[t][1][0], p[t][1][1], p[t][1][2], p[t][1][3]};
+                        const half8 p1 = {p[t][2][0], p[t][2][1], p[t][2][2], p[t][2][3], p[t][3][0], p[t][3][1], p[t][3][2], p[t][3][3]};
+                        o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, p0, o[t][dt], 0, 0, 0);
+                        o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, p1, o[t][dt], 0, 0, 0);
+                        o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(v2, p[t][4], o[t][dt], 0, 0, 0);
+                    }
+                }
+                // ---- normalise and store: lane (query fr, fq) holds d = dt*16 + fq*4 + 0..3 -------
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float l = __shfl(o[t][2][0], 32 + fr, 64);   // O^T row 40 = dt 2, fq 2, element 0
+                    const float inv = __builtin_amdgcn_rcpf(l);
+                    half_t* Orow = Ob + (size_t)((ip * 2 + t) * 16 + fr) * g.ldo + hh * XA_D;
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt) {
+                        if (dt == 2 && fq >= 2) continue;
+                        half4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[t][dt][r] * inv);
+                        *reinterpret_cast<half4*>(Orow + dt * 16 + fq * 4) = v;
+                    }
+                }
+            }
+        }
+    }
+#undef XA_DMA_TILE
+#undef XA_DMA_IMAGE
+#endif
+}
+
+extern "C" int fd_xattn_q_f16(const fd_xattn_desc* d, void* stream) {
+    if (fd_plan_recording() && d) {
+        const fd_xattn_desc dc_ = *d;
+        fd_plan_push([dc_](void* fd_s_) -> int { return fd_xattn_q_f16(&dc_, fd_s_); });
+    }
+    FD_CHECK_ARG(d && d->x && d->wq && d->bias && d->ln_colsum && d->ln_stats && d->k_image && d->v_image && d->out,
+                 FD_EINVAL, "fd_xattn_q_f16: null pointer");
+    FD_CHECK_ARG(d->heads == XA_HEADS && d->head_dim == XA_D, FD_ESHAPE,
+                 "fd_xattn_q_f16: 8 heads x 40 only (got %d x %d)", d->heads, d->head_dim);
+    FD_CHECK_ARG(d->M > 0 && d->M % 256 == 0 && d->rows_per_sample > 0 && d->rows_per_sample % 256 == 0 &&
+                     d->M % d->rows_per_sample == 0,
+                 FD_ESHAPE, "fd_xattn_q_f16: M=%d and rows_per_sample=%d must be multiples of 256", d->M, d->rows_per_sample);
+    FD_CHECK_ARG(d->n_keys > 64 && d->n_keys <= 80 && d->n_rep >= 1, FD_ESHAPE, "fd_xattn_q_f16: 65..80 keys, n_rep >= 1 (got %d keys)", d->n_keys);
+    FD_CHECK_ARG(d->ldx % 8 == 0 && d->ldw % 8 == 0 && d->ldo % 4 == 0 && d->ldx >= XA_C && d->ldw >= XA_C && d->ldo >= XA_C,
+                 FD_ESHAPE, "fd_xattn_q_f16: leading dimensions");
+    FD_CHECK_ARG((((uintptr_t)d->x | (uintptr_t)d->wq | (uintptr_t)d->k_image | (uintptr_t)d->v_image | (uintptr_t)d->bias |
+                   (uintptr_t)d->ln_colsum | (uintptr_t)d->ln_stats) % 16 == 0) && (uintptr_t)d->out % 8 == 0,
+                 FD_ESHAPE, "fd_xattn_q_f16: pointers must be 16-byte aligned");
+    const unsigned long long a_bytes = 2ull * ((unsigned long long)(d->M - 1) * d->ldx + XA_C);
+    const unsigned long long w_bytes = 2ull * ((unsigned long long)(XA_C - 1) * d->ldw + XA_C);
+    FD_CHECK_ARG(a_bytes < 0x7fffffffull, FD_ESHAPE, "fd_xattn_q_f16: hidden-state tensor >= 2 GiB");
+    XattnArgs g;
+    g.A = (const half_t*)d->x; g.W = (const half_t*)d->wq; g.bias = d->bias; g.colsum = d->ln_colsum;
+    g.ln_stats = d->ln_stats; g.kimg = (const char*)d->k_image; g.vimg = (const char*)d->v_image;
+    g.O = (half_t*)d->out;
+    g.M = d->M; g.lda = d->ldx; g.ldw = d->ldw; g.ldo = d->ldo;
+    g.rows_per_sample = d->rows_per_sample; g.nrep = d->n_rep;
+    g.samples_per_rep = d->M / d->rows_per_sample; g.n_keys = d->n_keys;
+    constexpr size_t lds = 2 * (size_t)(256 + 320) * 128 + (2 * 320 + 2 * 256) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xattn40), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // priced like the two launches it replaces: the q projection (GEMM family would count 2 M 320 320) and the
+    // attention proper (4 B heads Nq Nk d per replica)
+    const double flops = 2.0 * d->M * 320.0 * 320.0 + 4.0 * (double)d->n_rep * d->M * d->n_keys * XA_C;
+    fd_prof_begin(FD_FAMILY_ATTENTION, st, flops);
+    hipLaunchKernelGGL(k_xattn40, dim3(d->M / 256), dim3(1024), lds, st, g, (unsigned)a_bytes, (unsigned)w_bytes);
+    fd_prof_end(FD_FAMILY_ATTENTION, st);
+    FD_CHECK_LAUNCH("k_xattn40");
+    return FD_OK;
+}

@@ -45,6 +45,9 @@ _SIGNATURES = {
     'fd_guidance_header_pull': (c_int, [P, P, c_int, c_int, c_int, P]),
     'fd_gemm_f16': (c_int, [P, P]),
     'fd_attention_f16': (c_int, [P, P]),
+    'fd_xattn_image_bytes': (c_int64, [c_int, c_int]),
+    'fd_xattn_pack_kv_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, P]),
+    'fd_xattn_q_f16': (c_int, [P, P]),
     'fd_groupnorm_workspace_floats': (c_int64, [c_int, c_int]),
     'fd_groupnorm_nhwc_f16': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'fd_groupnorm_nhwc_ld_f16': (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),

@@ -347,6 +347,54 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, heads:
     return out
 
 
+class fd_xattn_desc(ctypes.Structure):
+    _fields_ = [('x', c_void_p), ('wq', c_void_p), ('bias', c_void_p), ('ln_colsum', c_void_p),
+                ('ln_stats', c_void_p), ('k_image', c_void_p), ('v_image', c_void_p), ('out', c_void_p),
+                ('M', c_int32), ('ldx', c_int32), ('ldw', c_int32), ('ldo', c_int32),
+                ('rows_per_sample', c_int32), ('n_rep', c_int32), ('n_keys', c_int32), ('heads', c_int32),
+                ('head_dim', c_int32)]
+
+
+def xattn_supported(heads: int, head_dim: int, n_keys: int, rows_per_sample: int) -> bool:
+    '''True when fd_xattn_q_f16 (fused LayerNorm-fold q projection + cross-attention) covers the shape.'''
+    return (os.environ.get('FD_UNET_XATTN', '1') != '0' and rows_per_sample % 256 == 0 and 64 < n_keys <= 80
+            and hip.lib().fd_xattn_image_bytes(heads, head_dim) > 0)
+
+
+def xattn_pack_kv(k: torch.Tensor, vt: torch.Tensor, samples: int, n_keys: int, heads: int, head_dim: int,
+                  out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    '''Context K [samples*n_keys][C] / V^T [samples][C][ldv] -> per-sample (K image, V^T image) in MFMA
+    fragment order (once per context; the images are what fd_xattn_q_f16 stages into LDS).'''
+    nbytes = hip.lib().fd_xattn_image_bytes(heads, head_dim)
+    assert nbytes > 0
+    if out is None:
+        out = (torch.empty((samples, nbytes), dtype=torch.uint8, device=k.device),
+               torch.empty((samples, nbytes), dtype=torch.uint8, device=k.device))
+    hip.call('fd_xattn_pack_kv_f16', k.data_ptr(), vt.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), samples,
+             n_keys, heads, head_dim, k.stride(0), vt.stride(1), n_keys * k.stride(0), vt.stride(0), hip.stream())
+    return out
+
+
+def xattn_q(x: torch.Tensor, w: LinW, ln_stats: torch.Tensor, images: Tuple[torch.Tensor, torch.Tensor],
+            rows_per_sample: int, n_keys: int, heads: int, head_dim: int, n_rep: int = 1,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    '''softmax(LN-fold(x) Wq^T  K^T) V over the packed context for `n_rep` context replicas sharing the
+    queries: x [M][C] un-normalised fp16 -> [n_rep*M][C] fp16.  `w` from prep_linear_ln with the softmax
+    scale * log2(e) folded in.'''
+    M, C = x.shape
+    assert w.colsum is not None and w.bias is not None and ln_stats.shape == (M, 2) and x.stride(1) == 1
+    assert images[0].shape[0] == n_rep * (M // rows_per_sample)
+    if out is None:
+        out = _empty((n_rep * M, C), torch.float16, x)
+    d = fd_xattn_desc()
+    d.x, d.wq, d.bias, d.ln_colsum = x.data_ptr(), w.w.data_ptr(), w.bias.data_ptr(), w.colsum.data_ptr()
+    d.ln_stats, d.k_image, d.v_image, d.out = ln_stats.data_ptr(), images[0].data_ptr(), images[1].data_ptr(), out.data_ptr()
+    d.M, d.ldx, d.ldw, d.ldo = M, x.stride(0), w.w.stride(0), out.stride(0)
+    d.rows_per_sample, d.n_rep, d.n_keys, d.heads, d.head_dim = rows_per_sample, n_rep, n_keys, heads, head_dim
+    hip.call('fd_xattn_q_f16', ctypes.byref(d), hip.stream())
+    return out
+
+
 # ---------------------------------------------------------------------------------- norms
 _gn_ws = {}
 

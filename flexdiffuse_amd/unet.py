@@ -85,6 +85,7 @@ class _Attn:
         self.ff2 = ops.prep_linear(g(f'{tb}.ff.net.2.weight'), g(f'{tb}.ff.net.2.bias'), dev)
         self.C = self.q2.N
         self.ctx_kv = None  # (K [Be*L][C], V^T [Be][C][ldv]) of the cached text context
+        self.ctx_img = None  # the same context packed for the fused q-projection + cross-attention kernel
 
 
 class UNetOutput(SimpleNamespace):
@@ -221,7 +222,13 @@ class UNet2DConditionModel():
                 ops.gemm_vt(c16, a.v2, Be, L, ldv, out=old[1])
             else:
                 a.ctx_kv = (ops.gemm(c16, a.k2), ops.gemm_vt(c16, a.v2, Be, L, ldv), L)
+                a.ctx_img = None
                 realloc = True
+            # 8 heads x 40 (the 64x64 level): K / V^T also packed in MFMA fragment order for fd_xattn_q_f16
+            if a.ln_fold and a.q_pre and ops.xattn_supported(a.heads, a.C // a.heads, L, 256):
+                a.ctx_img = ops.xattn_pack_kv(a.ctx_kv[0], a.ctx_kv[1], Be, L, a.heads, a.C // a.heads, out=a.ctx_img)
+            else:
+                a.ctx_img = None
         if realloc:
             self.ctx_generation += 1
         self._ctx_key = key
@@ -263,19 +270,25 @@ class UNet2DConditionModel():
         o = ops.attention(q, k, vt, B, a.heads, HW, HW, d, q_prescaled=a.q_pre)
         st = mkst(B * HW)
         h = ops.gemm(o, a.o1, residual=h, ln_stats_out=st)
-        if a.ln_fold:
-            q2 = ops.gemm(h, a.q2, ln_stats=st if st is not None else ops.ln_row_stats(h))
-        else:
-            q2 = ops.gemm(ops.layernorm(h, *a.ln[1]), a.q2)
         kc, vtc, L = a.ctx_kv
         xt = x.t
-        if rep == 1:
-            o = ops.attention(q2, kc, vtc, B, a.heads, HW, L, d, q_prescaled=a.q_pre)
+        if a.ctx_img is not None and st is not None and HW % 256 == 0:
+            # q projection + cross-attention in one launch (the query matrix never goes to HBM); `rep`
+            # context replicas share the queries
+            o = ops.xattn_q(h, a.q2, st, a.ctx_img, HW, L, a.heads, d, n_rep=rep)
         else:
-            o = torch.empty((rep * B * HW, C), dtype=torch.float16, device=q2.device)
-            for r in range(rep):
-                ops.attention(q2, kc[r * B * L:(r + 1) * B * L], vtc[r * B:(r + 1) * B], B, a.heads,
-                              HW, L, d, q_prescaled=a.q_pre, out=o[r * B * HW:(r + 1) * B * HW])
+            if a.ln_fold:
+                q2 = ops.gemm(h, a.q2, ln_stats=st if st is not None else ops.ln_row_stats(h))
+            else:
+                q2 = ops.gemm(ops.layernorm(h, *a.ln[1]), a.q2)
+            if rep == 1:
+                o = ops.attention(q2, kc, vtc, B, a.heads, HW, L, d, q_prescaled=a.q_pre)
+            else:
+                o = torch.empty((rep * B * HW, C), dtype=torch.float16, device=q2.device)
+                for r in range(rep):
+                    ops.attention(q2, kc[r * B * L:(r + 1) * B * L], vtc[r * B:(r + 1) * B], B, a.heads,
+                                  HW, L, d, q_prescaled=a.q_pre, out=o[r * B * HW:(r + 1) * B * HW])
+        if rep > 1:
             h, xt, B = ops.repeat_rows(h, rep), ops.repeat_rows(xt, rep), rep * B
         st = mkst(B * HW)
         h = ops.gemm(o, a.o2, residual=h, ln_stats_out=st)

@@ -212,6 +212,34 @@ typedef struct fd_attention_desc {
 
 int fd_attention_f16(const fd_attention_desc* desc, void* stream);
 
+/* Fused front half of the UNet's cross-attention at the 64x64 level (8 heads x 40 channels): the
+ * LayerNorm-fold q projection and softmax(Q K^T) V over the step-invariant text context (65..80
+ * keys) in ONE launch -- replaces the q-projection fd_gemm_f16 launch and the fd_attention_f16
+ * launch of diffusers' BasicTransformerBlock.attn2 inside `unet(...)` (reference
+ * pipeline/guide.py:56-58); the query matrix never goes to HBM.
+ * fd_xattn_pack_kv_f16 packs the context's K [samples][n_keys][ldk] / V^T [samples][heads*head_dim][ldvt]
+ * (the outputs of the to_k / to_v projections, computed once per context) into per-sample "images"
+ * in MFMA fragment order, fd_xattn_image_bytes(heads, head_dim) bytes each (0 = unsupported shape). */
+int64_t fd_xattn_image_bytes(int heads, int head_dim);
+int fd_xattn_pack_kv_f16(const void* K, const void* Vt, void* k_image, void* v_image, int samples, int n_keys,
+                         int heads, int head_dim, int ldk, int ldvt, int64_t k_sample_stride,
+                         int64_t vt_sample_stride, void* stream);
+typedef struct fd_xattn_desc {
+    const void* x;          /* fp16 [M][ldx] UN-normalised hidden states */
+    const void* wq;         /* fp16 [C][ldw] q weights with the LayerNorm gain and head_dim^-0.5 log2(e) folded in */
+    const float* bias;      /* [C] folded bias (W beta), see fd_gemm_desc.ln_stats */
+    const float* ln_colsum; /* [C] */
+    const float* ln_stats;  /* [M][2] (rstd, -mean rstd) of the rows of x */
+    const void* k_image;    /* [n_rep * M / rows_per_sample] images: replica r of sample b at index r * (M / rows_per_sample) + b */
+    const void* v_image;
+    void* out;              /* fp16 [n_rep * M][ldo]: attention output (heads concatenated), replica-major */
+    int32_t M, ldx, ldw, ldo;
+    int32_t rows_per_sample; /* query rows per sample; a multiple of 256 */
+    int32_t n_rep;           /* context replicas sharing the same queries (CFG fan-out of a shared prefix); >= 1 */
+    int32_t n_keys, heads, head_dim;
+} fd_xattn_desc;
+int fd_xattn_q_f16(const fd_xattn_desc* desc, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Normalisation / softmax (HBM-bound)
  * ---------------------------------------------------------------------------------- */

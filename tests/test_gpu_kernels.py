@@ -441,3 +441,57 @@ def test_gemm_emits_row_stats_of_its_output(dev, M, res):
     assert not ops.can_emit_row_stats(M, 640)
     with pytest.raises(ValueError):
         ops.gemm(a[:, :K], ops.prep_linear(torch.zeros((640, K)), None, dev), ln_stats_out=st)
+
+
+@pytest.mark.parametrize('B,HW,rep,L', [(2, 4096, 1, 77), (1, 1024, 2, 77), (3, 256, 1, 65), (2, 512, 2, 80)])
+def test_fused_q_projection_cross_attention(dev, B, HW, rep, L):
+    '''fd_xattn_q_f16: LayerNorm-fold q projection + softmax(Q K^T) V over a packed 65..80-key context in
+    ONE launch (8 heads x 40) vs (a) the two launches it replaces -- fd_gemm_f16 with ln_stats, then
+    fd_attention_f16 with q_prescaled -- and (b) a torch fp32 reference of LayerNorm -> to_q ->
+    attention.  Q is rounded to fp16 identically in both device paths; the attention proper differs in
+    MFMA summation order (channel / key permutations inside the fragments) and in the softmax
+    reference point (exact row max here, first-tile lazy max there), so (a) is a few fp16 ulps, not
+    bit-level.  `rep` > 1: context replicas sharing the queries (the CFG fan-out of the shared prefix).'''
+    from flexdiffuse_amd import ops
+    C, heads, d = 320, 8, 40
+    M = B * HW
+    g = torch.Generator().manual_seed(B * HW + rep + L)
+    x = (torch.randn((M, C), generator=g) * (0.5 + torch.rand((M, 1), generator=g) * 2) +
+         torch.randn((M, 1), generator=g) * 1.5).half()
+    gamma = 1.0 + 0.3 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    wq = torch.randn((C, C), generator=g) * C ** -0.5 * 1.5
+    qs = ops.QK_LOG2E * d ** -0.5
+    lw = ops.prep_linear_ln(wq * qs, None, gamma, beta, dev)
+    k = (torch.randn((rep * B * L, C), generator=g) * 1.2).half()
+    v = torch.randn((rep * B, L, C), generator=g).half()
+    ldv = (L + 7) // 8 * 8
+    vt = torch.zeros((rep * B, C, ldv), dtype=torch.float16)
+    vt[:, :, :L] = v.permute(0, 2, 1)
+    xd, kd, vtd = x.to(dev), k.to(dev), vt.to(dev)
+    st = ops.ln_row_stats(xd)
+    assert ops.xattn_supported(heads, d, L, HW)
+    img = ops.xattn_pack_kv(kd, vtd, rep * B, L, heads, d)
+    got = ops.xattn_q(xd, lw, st, img, HW, L, heads, d, n_rep=rep).float().cpu()
+    assert got.shape == (rep * M, C) and bool(torch.isfinite(got).all())
+    # (a) the unfused device path
+    q = ops.gemm(xd, lw, ln_stats=st)
+    for r in range(rep):
+        o = ops.attention(q, kd[r * B * L:(r + 1) * B * L], vtd[r * B:(r + 1) * B], B, heads, HW, L, d,
+                          q_prescaled=True).float().cpu()
+        err = (got[r * M:(r + 1) * M] - o).abs()
+        assert float(err.max()) <= 4e-3 * float(o.abs().max()) + 1e-3, (r, float(err.max()), float(o.abs().max()))
+    # (b) torch fp32: LayerNorm -> to_q -> softmax(q k^T / sqrt d) v per head
+    xn = torch.nn.functional.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    qf = (xn @ wq.T).view(B, HW, heads, d).permute(0, 2, 1, 3)
+    for r in range(rep):
+        kf = k[r * B * L:(r + 1) * B * L].float().view(B, L, heads, d).permute(0, 2, 1, 3)
+        vf = v[r * B:(r + 1) * B].float().view(B, L, heads, d).permute(0, 2, 1, 3)
+        p = torch.softmax(qf @ kf.transpose(-1, -2) * d ** -0.5, dim=-1)
+        want = (p @ vf).permute(0, 2, 1, 3).reshape(M, C)
+        e = float((got[r * M:(r + 1) * M] - want).abs().max())
+        assert e <= 2e-2 * float(want.abs().max()), (r, e, float(want.abs().max()))
+    if rep == 2:   # the replicas really saw different contexts
+        assert float((got[:M] - got[M:]).abs().max()) > 0.05
+    assert not ops.xattn_supported(8, 80, L, HW) and not ops.xattn_supported(heads, d, 64, HW)
+    assert not ops.xattn_supported(heads, d, L, 64)
