@@ -122,8 +122,31 @@ extern "C" int64_t fd_xattn_image_bytes(int heads, int head_dim) {
     return (heads == XA_HEADS && head_dim == XA_D) ? (int64_t)XA_KIMG : 0;   // K and V^T images have the same size
 }
 
+// The 16-wide remainder of a contraction (8 channels of head dim 40; keys 64..79).  The image keeps
+// it as 4 halfs per lane (half the LDS bytes of a K = 32 fragment); the MFMA is the K = 32 form on
+// zero-extended operands: v_mfma_f32_16x16x16_f16 occupies the matrix pipe just as long
+// (profiles/r02_micro_mfma_k16.txt), and a dependent chain that MIXES the two forms on one
+// accumulator gave run-to-run different sums here (FD_XATTN_K16=1 builds that form for the record).
+#ifndef FD_XATTN_K16
+#define FD_XATTN_K16 0
+#endif
+__device__ __forceinline__ floatx4 xa_mfma_tail(half4 a, half4 b, floatx4 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#if FD_XATTN_K16
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+#else
+    const half_t z = (half_t)0.f;
+    const half8 a8 = {a[0], a[1], a[2], a[3], z, z, z, z}, b8 = {b[0], b[1], b[2], b[3], z, z, z, z};
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, c, 0, 0, 0);
+#endif
+#else
+    return c;
+#endif
+}
+#define XA_MFMA_TAIL(A4, B4, C) xa_mfma_tail((A4), (B4), (C))
+
 // ---- the fused kernel -------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes, unsigned w_bytes) {
+__global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes, unsigned w_bytes, unsigned o_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 256, BN = 320, WM = 4, WN = 4, NW = 16;
     constexpr int WTM = 64, WTN = 80, MI = 4, NI = 5;
@@ -193,9 +216,11 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    const int sample = m0 / g.rows_per_sample;   // the tile lies in one sample (rows_per_sample % 256 == 0)
-    __amdgpu_buffer_rsrc_t rsKi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.kimg + (size_t)sample * XA_KIMG), 0, XA_KIMG, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsVi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.vimg + (size_t)sample * XA_VIMG), 0, XA_VIMG, 0x00020000);
+    const int rep = blockIdx.y;
+    // the tile lies in one sample (rows_per_sample % 256 == 0); replica r of sample b is image r * samples + b
+    const size_t sample = (size_t)rep * g.samples_per_rep + m0 / g.rows_per_sample;
+    const __amdgpu_buffer_rsrc_t rsKi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.kimg + sample * XA_KIMG), 0, XA_KIMG, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsVi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.vimg + sample * XA_VIMG), 0, XA_VIMG, 0x00020000);
 
     XA_DMA_TILE(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -236,8 +261,10 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
     const char* sV = smem + (cur ^ 1) * STAGE;
     XA_DMA_IMAGE(rsVi, cur ^ 1);
 
-    // ---- Q = LN-fold(acc) rounded to fp16 (exactly what the unfused q projection stores) -------
-    half4 qh[MI][NI];
+    // ---- Q = LN-fold(acc) rounded to fp16 (exactly what the unfused q projection stores), held directly as
+    // MFMA B operands: qA = fragments {0,1} (head A, channels 0..31), qB = fragments {3,4} (head B, channels
+    // 8..39), qT = fragment 2 zero-extended (A's channels 32..39 | B's channels 0..7) -------------------------
+    half8 qA[MI], qB[MI], qT[MI];
     {
         floatx2 st[MI];
 #pragma unroll
@@ -251,30 +278,28 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    qh[i][j][r] = (half_t)fmaf(acc[i][j][r], st[i][0], fmaf(st[i][1], cs[r], bb[r]));
+                for (int r = 0; r < 4; ++r) {
+                    const half_t q = (half_t)fmaf(acc[i][j][r], st[i][0], fmaf(st[i][1], cs[r], bb[r]));
+                    if (j == 0) qA[i][r] = q;
+                    if (j == 1) qA[i][4 + r] = q;
+                    if (j == 2) { qT[i][r] = q; qT[i][4 + r] = (half_t)0.f; }
+                    if (j == 3) qB[i][r] = q;
+                    if (j == 4) qB[i][4 + r] = q;
+                }
+            // one fragment column at a time: its accumulators die as its q halves are born (left alone the
+            // scheduler converts everything at once: 80 accumulators + 48 operand registers live -> spills)
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-
     const int kb_last_valid = g.n_keys - 64 - fq * 4;   // key 64 + fq*4 + r is real iff r < kb_last_valid
-#pragma unroll 1
-    for (int rep = 0; rep < g.nrep; ++rep) {
-        if (rep > 0) {
-            // next replica of the context (CFG fan-out of a shared prefix): swap both images
-            __syncthreads();
-            const size_t s2 = (size_t)(rep * g.samples_per_rep + sample);
-            rsKi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.kimg + s2 * XA_KIMG), 0, XA_KIMG, 0x00020000);
-            rsVi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.vimg + s2 * XA_VIMG), 0, XA_VIMG, 0x00020000);
-            XA_DMA_IMAGE(rsKi, cur);
-            XA_DMA_IMAGE(rsVi, cur ^ 1);
-        }
-        bool v_ready = false;
-        if (rep > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            v_ready = true;
-        }
-        half_t* Ob = g.O + ((size_t)rep * g.M + m0 + wm * WTM) * g.ldo + wn * WTN;
+    // output through a buffer descriptor: 32-bit per-lane offsets instead of 64-bit pointers in VGPRs
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)g.O, 0, o_bytes, 0x00020000);
+    const unsigned o_lane = (unsigned)(((m0 + wm * WTM + fr) * g.ldo + wn * WTN + fq * 4) * 2);
+    // context replicas sharing the queries (CFG fan-out of a shared prefix) are a grid dimension: the q tile is
+    // recomputed per replica -- at those shapes (8 samples) half the CUs would otherwise idle
+    bool v_ready = false;
+    const unsigned o_rep = (unsigned)rep * (unsigned)g.M * (unsigned)g.ldo * 2u;   // scalar byte offset of the replica
+    {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const char* kh = sK + (wn * 2 + hh) * XA_KHEAD;
@@ -287,17 +312,18 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
                 for (int kb = 0; kb < XA_KB; ++kb) {
                     const half8 k32 = *reinterpret_cast<const half8*>(kh + kb * 1536 + lane * 16);
                     const half4 k16 = *reinterpret_cast<const half4*>(kh + kb * 1536 + 1024 + lane * 8);
+                    const half_t z = (half_t)0.f;
+                    const half8 k16x = {k16[0], k16[1], k16[2], k16[3], z, z, z, z};
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int i = ip * 2 + t;
-                        const half4 qa = qh[i][hh ? 3 : 0], qb = qh[i][hh ? 4 : 1];
-                        const half8 q32 = {qa[0], qa[1], qa[2], qa[3], qb[0], qb[1], qb[2], qb[3]};
-                        floatx4 v = __builtin_amdgcn_mfma_f32_16x16x32_f16(k32, q32, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        s[t][kb] = __builtin_amdgcn_mfma_f32_16x16x16f16(k16, qh[i][2], v, 0, 0, 0);
+                        const floatx4 v = __builtin_amdgcn_mfma_f32_16x16x32_f16(k32, hh ? qB[i] : qA[i], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        s[t][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k16x, qT[i], v, 0, 0, 0);
                     }
                 }
-                // ---- softmax over the n_keys keys (base-2 logits: the scale is folded into Wq) ----
-                half4 p[2][XA_KB];
+                // ---- softmax over the n_keys keys (base-2 logits: the scale is folded into Wq); P held as the
+                // B operands of the PV product: pk[t][kg] = key blocks {2 kg, 2 kg + 1}, block 4 zero-extended ----
+                half8 pk[2][3];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -312,7 +338,10 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
 #pragma unroll
                     for (int kb = 0; kb < XA_KB; ++kb)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) p[t][kb][r] = (half_t)__builtin_amdgcn_exp2f(s[t][kb][r] - mx);
+                        for (int r = 0; r < 4; ++r)
+                            pk[t][kb >> 1][(kb & 1) * 4 + r] = (half_t)__builtin_amdgcn_exp2f(s[t][kb][r] - mx);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk[t][2][4 + r] = (half_t)0.f;
                 }
                 if (!v_ready) {   // first use of the V^T image in this launch
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -322,21 +351,17 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
                 // ---- O^T = V^T P^T (row 40 of the image is all ones: the softmax denominator) ----
                 floatx4 o[2][3];
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int dt = 0; dt < 3; ++dt) o[t][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
                 for (int dt = 0; dt < 3; ++dt) {
                     const half8 v0 = *reinterpret_cast<const half8*>(vh + dt * 2560 + lane * 16);
                     const half8 v1 = *reinterpret_cast<const half8*>(vh + dt * 2560 + 1024 + lane * 16);
                     const half4 v2 = *reinterpret_cast<const half4*>(vh + dt * 2560 + 2048 + lane * 8);
+                    const half_t z = (half_t)0.f;
+                    const half8 v2x = {v2[0], v2[1], v2[2], v2[3], z, z, z, z};
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const half8 p0 = {p[t][0][0], p[t][0][1], p[t][0][2], p[t][0][3], p[t][1][0], p[t][1][1], p[t][1][2], p[t][1][3]};
-                        const half8 p1 = {p[t][2][0], p[t][2][1], p[t][2][2], p[t][2][3], p[t][3][0], p[t][3][1], p[t][3][2], p[t][3][3]};
-                        o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, p0, o[t][dt], 0, 0, 0);
-                        o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, p1, o[t][dt], 0, 0, 0);
-                        o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(v2, p[t][4], o[t][dt], 0, 0, 0);
+                        floatx4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, pk[t][0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, pk[t][1], a, 0, 0, 0);
+                        o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v2x, pk[t][2], a, 0, 0, 0);
                     }
                 }
                 // ---- normalise and store: lane (query fr, fq) holds d = dt*16 + fq*4 + 0..3 -------
@@ -344,14 +369,15 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
                 for (int t = 0; t < 2; ++t) {
                     const float l = __shfl(o[t][2][0], 32 + fr, 64);   // O^T row 40 = dt 2, fq 2, element 0
                     const float inv = __builtin_amdgcn_rcpf(l);
-                    half_t* Orow = Ob + (size_t)((ip * 2 + t) * 16 + fr) * g.ldo + hh * XA_D;
+                    const unsigned off = o_lane + (unsigned)(((ip * 2 + t) * 16 * g.ldo + hh * XA_D) * 2);
 #pragma unroll
                     for (int dt = 0; dt < 3; ++dt) {
-                        if (dt == 2 && fq >= 2) continue;
                         half4 v;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[t][dt][r] * inv);
-                        *reinterpret_cast<half4*>(Orow + dt * 16 + fq * 4) = v;
+                        // dt 2: only d 32..39 (fq < 2) exist; the other lanes aim past the descriptor (dropped)
+                        const unsigned vo = (dt == 2 && fq >= 2) ? 0xffffff00u : off + dt * 32;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xu32x2, v), rsO, vo, o_rep, 0);
                     }
                 }
             }
@@ -399,9 +425,12 @@ extern "C" int fd_xattn_q_f16(const fd_xattn_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // priced like the two launches it replaces: the q projection (GEMM family would count 2 M 320 320) and the
     // attention proper (4 B heads Nq Nk d per replica)
-    const double flops = 2.0 * d->M * 320.0 * 320.0 + 4.0 * (double)d->n_rep * d->M * d->n_keys * XA_C;
+    const double flops = 2.0 * d->M * 320.0 * 320.0 + 4.0 * (double)d->n_rep * d->M * d->n_keys * XA_C;   // q priced once
     fd_prof_begin(FD_FAMILY_ATTENTION, st, flops);
-    hipLaunchKernelGGL(k_xattn40, dim3(d->M / 256), dim3(1024), lds, st, g, (unsigned)a_bytes, (unsigned)w_bytes);
+    const unsigned long long o_bytes = 2ull * ((unsigned long long)((long long)d->n_rep * d->M - 1) * d->ldo + XA_C);
+    FD_CHECK_ARG(o_bytes < 0x7fffffffull, FD_ESHAPE, "fd_xattn_q_f16: output tensor >= 2 GiB");
+    hipLaunchKernelGGL(k_xattn40, dim3(d->M / 256, d->n_rep), dim3(1024), lds, st, g, (unsigned)a_bytes, (unsigned)w_bytes,
+                       (unsigned)o_bytes);
     fd_prof_end(FD_FAMILY_ATTENTION, st);
     FD_CHECK_LAUNCH("k_xattn40");
     return FD_OK;
