@@ -1468,6 +1468,17 @@ static int launch_epi(GemmArgs& g, int batch, hipStream_t st) {
     return launch<BM, BN, false, WM, NS, WN, 0>(g, batch, st);
 }
 
+// 1 when fd_gemm_f16 can honour fd_gemm_desc.ln_stats_out for an [M][N] fp16 output with row stride ldc and
+// (ldr > 0) a residual of row stride ldr: the row-complete 256x320 tile on the LDS-DMA path with the lean
+// epilogue and LDS-staged biases (FD_GEMM_FAST_EPI / FD_GEMM_BIAS_LDS / FD_GEMM_NO_DMA are A/B switches that
+// take those away).  Callers that get 0 run fd_ln_row_stats_f16 on the output instead.
+extern "C" int fd_gemm_can_emit_row_stats(int M, int N, int K, int ldc, int ldr) {
+    if (!(g_use_dma && g_fast_epi && g_bias_lds)) return 0;
+    if (N != 320 || M <= 0 || M % 256 != 0 || K <= 0 || K % 8 != 0) return 0;
+    if (ldc < N || (ldc & 7) != 0 || (ldr != 0 && (ldr < N || (ldr & 3) != 0))) return 0;
+    return 2ull * ((unsigned long long)(M - 1) * (unsigned long long)ldc + N) < 0x7fffffffull ? 1 : 0;
+}
+
 extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     if (fd_plan_recording() && d) {
         const fd_gemm_desc dc_ = *d;
@@ -1528,6 +1539,10 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                                 "output, act NONE or GEGLU, alpha 1");
         FD_CHECK_ARG(((uintptr_t)d->ln_stats % 16 == 0) && ((uintptr_t)d->ln_colsum % 16 == 0), FD_ESHAPE,
                      "fd_gemm_f16: ln_stats / ln_colsum must be 16-byte aligned");
+        // transposed store: a lane folds 4 consecutive rows with two 16-byte statistics loads (row block clamped
+        // to M - 4): a ragged last block would shift the statistics onto the wrong rows
+        FD_CHECK_ARG(!d->trans_out || d->M % 4 == 0, FD_ESHAPE,
+                     "fd_gemm_f16: ln_stats with trans_out needs M %% 4 == 0 (got M=%d)", d->M);
         g.ln_stats = d->ln_stats;
         g.bias2 = d->ln_colsum;   // one row for every sample: row stride 0
         g.ldb2 = 0;
@@ -1623,8 +1638,10 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     // stage (two K-tiles in flight) gives -10 % at K = 1280, -22 % at K = 2560 (vs 256x160 + split-K 2),
     // -3 % at K = 5120 (tools/ab_ns3.py).  Convolutions and M >= 16 k lose with it (one workgroup per CU).
     // ... unless 256x160 tiles already give every CU one tile (N = 2560, the fused q|k projection: 33 vs 41.5 us)
+    // (only where its own 128x160 tiles fill most of the chip: swept at N >= 1280; a narrow N -- e.g. the batch-1
+    // 4096x320x1280 FF-out -- would leave 64 workgroups on 256 CUs with split-K switched off)
     if (g.mode != MODE_CONV && n160 && g.M > 2048 && g.M <= 4096 && g.K >= 1280 && batch == 1 &&
-        (long long)fd_cdiv(g.M, 256) * (g.N / 160) < 256) {
+        (long long)fd_cdiv(g.M, 256) * (g.N / 160) < 256 && (long long)fd_cdiv(g.M, 128) * (g.N / 160) >= 200) {
         best_tile = 20;
         best_split = 1;
     }
@@ -1652,6 +1669,10 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                      "fd_gemm_f16: operand of %llu elements exceeds the 2^31-element addressing limit; "
                      "split the batch", a_elems > w_elems ? a_elems : w_elems);
         if (2 * a_elems >= 0x7fffffffull || 2 * w_elems >= 0x7fffffffull) {
+            // the register-staged kernel knows neither the LayerNorm fold nor the producer statistics: refuse
+            // rather than hand the consumer GEMM uninitialised statistics
+            FD_CHECK_ARG(!g.ln_stats && !g.ln_stats_out, FD_ESHAPE,
+                         "fd_gemm_f16: ln_stats / ln_stats_out need the LDS-DMA path (operands < 2 GiB); split the batch");
             best_tile = geglu ? 1 : (g.N % 160 == 0 ? 2 : 1);   // 128x160 / 128x128, 4 waves
             if (g.N <= 64) best_tile = 3;
         }

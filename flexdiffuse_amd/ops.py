@@ -125,10 +125,12 @@ def prep_linear_ln(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tens
     return lw
 
 
-def can_emit_row_stats(M: int, N: int) -> bool:
+def can_emit_row_stats(M: int, N: int, K: int = 320, ldc: int = 0, ldr: int = 0) -> bool:
     '''True when fd_gemm_f16 can write the LayerNorm statistics of its output rows itself
-    (fd_gemm_desc.ln_stats_out: one 256x320 tile spans the whole row).'''
-    return N == 320 and M % 256 == 0
+    (fd_gemm_desc.ln_stats_out: one 256x320 tile spans the whole row, lean epilogue on the LDS-DMA
+    path).  The library answers, so its A/B switches (FD_GEMM_FAST_EPI=0, FD_GEMM_BIAS_LDS=0,
+    FD_GEMM_NO_DMA) degrade to the separate statistics pass instead of an FD_ESHAPE.'''
+    return bool(hip.lib().fd_gemm_can_emit_row_stats(M, N, K, ldc or N, ldr))
 
 
 def ln_row_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

@@ -76,13 +76,34 @@ class CLIPBPETokenizer():
     non-space characters) -> UTF-8 bytes as printable characters, the last one of each piece
     carrying "</w>" -> greedy lowest-rank pair merges -> vocabulary ids.  Rows are
     `[BOS] ids [EOS]`, truncated so that EOS survives, padded with `pad_token` (the EOS token
-    for SD1.x; "!" = id 0 for the SD2.x tokenizer).'''
+    for SD1.x; "!" = id 0 for the SD2.x tokenizer).
+
+    Which Hugging Face path this mirrors.  `text_cleanup='fast'` (default) is the pipeline of
+    the `tokenizers`-backed CLIPTokenizer (`CLIPTokenizerFast`; the only CLIPTokenizer of
+    transformers >= 5): normalizers NFC -> `\\s+` -> " " -> lower case, then the piece pattern
+    -- checked id-for-id against the installed transformers in tests/test_tokenizer.py, CJK
+    and control characters included.  The reference pins transformers 4.21.1 and calls the SLOW
+    `CLIPTokenizer` (utils.py:61-63) without `ftfy` in its requirements; that class then runs
+    BERT's BasicTokenizer first, which additionally DROPS control / NUL / U+FFFD characters and
+    puts spaces around every CJK ideograph (so a CJK run becomes one piece per character).
+    `text_cleanup='basic'` restates those two clean-ups (from the published BasicTokenizer
+    algorithm; transformers 4.21.1 is not installed, so only known answers pin it).  The two
+    modes agree on every prompt without such characters.  Needs the third-party `regex`
+    module (Unicode property classes in the piece pattern), as transformers' own slow
+    tokenizer does.'''
 
     BOS, EOS = '<|startoftext|>', '<|endoftext|>'
 
     def __init__(self, vocab: Dict[str, int], merges: Iterable[Union[str, Sequence[str]]],
-                 model_max_length: int = 77, pad_token: Optional[str] = None):
-        import regex
+                 model_max_length: int = 77, pad_token: Optional[str] = None, text_cleanup: str = 'fast'):
+        try:
+            import regex
+        except ImportError as ex:      # pragma: no cover
+            raise ImportError('CLIPBPETokenizer needs the `regex` package (\\p{L} / \\p{N} classes in '
+                              "CLIP's piece pattern)") from ex
+        if text_cleanup not in ('fast', 'basic'):
+            raise ValueError("text_cleanup must be 'fast' or 'basic'")
+        self.text_cleanup = text_cleanup
         self.vocab = dict(vocab)
         pairs = []
         for m in merges:
@@ -149,7 +170,33 @@ class CLIPBPETokenizer():
         self._memo[piece] = sym
         return sym
 
+    @staticmethod
+    def _is_cjk(cp: int) -> bool:
+        return (0x4E00 <= cp <= 0x9FFF or 0x3400 <= cp <= 0x4DBF or 0x20000 <= cp <= 0x2A6DF or
+                0x2A700 <= cp <= 0x2B73F or 0x2B740 <= cp <= 0x2B81F or 0x2B820 <= cp <= 0x2CEAF or
+                0xF900 <= cp <= 0xFAFF or 0x2F800 <= cp <= 0x2FA1F)
+
+    @classmethod
+    def _basic_clean(cls, text: str) -> str:
+        '''BasicTokenizer's two clean-ups (see the class docstring): drop NUL / U+FFFD / control
+        characters (category C*, except tab / newline / carriage return, which count as whitespace),
+        map whitespace to a space, and put spaces around CJK ideographs.'''
+        out = []
+        for ch in text:
+            cp = ord(ch)
+            if ch in '\t\n\r' or ch == ' ' or unicodedata.category(ch) == 'Zs':
+                out.append(' ')
+            elif cp == 0 or cp == 0xFFFD or unicodedata.category(ch).startswith('C'):
+                continue
+            elif cls._is_cjk(cp):
+                out.append(' ' + ch + ' ')
+            else:
+                out.append(ch)
+        return ''.join(out)
+
     def tokenize(self, text: str) -> List[str]:
+        if self.text_cleanup == 'basic':
+            text = self._basic_clean(text)
         text = self._space.sub(' ', unicodedata.normalize('NFC', text)).lower()
         out: List[str] = []
         for piece in self._pieces.findall(text):

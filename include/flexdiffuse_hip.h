@@ -189,6 +189,9 @@ typedef struct fd_gemm_desc {
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);
+/* 1 when fd_gemm_f16 will honour ln_stats_out for an [M][N] fp16 output (row stride ldc, residual row
+ * stride ldr or 0) with the library's current settings, else 0: then run fd_ln_row_stats_f16 on the output. */
+int fd_gemm_can_emit_row_stats(int M, int N, int K, int ldc, int ldr);
 
 /* Flash attention forward (scores never leave registers).  Q [B][n_q][ldq], K [B][n_k][ldk]
  * with head h at column h*head_dim; Vt [B][heads*head_dim][ldvt] is V transposed (keys

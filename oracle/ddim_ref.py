@@ -24,8 +24,10 @@ def timesteps(num_inference_steps: int, n_train=1000, steps_offset=0) -> np.ndar
 
 
 def ddim_step(eps, t: int, x, acp, num_inference_steps, n_train=1000, set_alpha_to_one=False,
-              prediction_type='epsilon'):
-    '''eta = 0 deterministic DDIM update x_t -> x_{t-1}.'''
+              prediction_type='epsilon', eta: float = 0.0, noise=None):
+    '''DDIM update x_t -> x_{t-1} (DDIM paper eq. 12).  eta = 0: deterministic.  eta > 0 (the reference passes
+    it through, pipeline/flex.py:247-251,280-285): sigma_t = eta sqrt((1 - a_prev) / (1 - a_t)) sqrt(1 - a_t / a_prev),
+    the direction term shrinks to sqrt(1 - a_prev - sigma_t^2) eps and sigma_t * `noise` is added.'''
     prev = t - n_train // num_inference_steps
     a_t = acp[t]
     a_prev = acp[prev] if prev >= 0 else (torch.tensor(1.0) if set_alpha_to_one else acp[0])
@@ -34,7 +36,10 @@ def ddim_step(eps, t: int, x, acp, num_inference_steps, n_train=1000, set_alpha_
         eps = a_t.sqrt() * eps + (1 - a_t).sqrt() * x
     else:
         x0 = (x - (1 - a_t).sqrt() * eps) / a_t.sqrt()
-    return a_prev.sqrt() * x0 + (1 - a_prev).sqrt() * eps
+    if not eta:
+        return a_prev.sqrt() * x0 + (1 - a_prev).sqrt() * eps
+    sigma = eta * (((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)).sqrt()
+    return a_prev.sqrt() * x0 + (1 - a_prev - sigma ** 2).sqrt() * eps + sigma * noise
 
 
 def add_noise(x, noise, t, acp):

@@ -32,8 +32,9 @@ def noise_pred(sd_unet, ucfg, latents, t, embeds, uncond, guidance, unet_fn=None
 
 @torch.no_grad()
 def denoise(sd_unet, ucfg, embeds, uncond, latents, steps, guidance, steps_offset=0, t_start=0,
-            callback=None):
-    '''pipeline/flex.py:262-287 with DDIM (eta = 0).  Returns (final latents, timesteps used).'''
+            callback=None, eta=0.0, noise_fn=None):
+    '''pipeline/flex.py:262-287 with DDIM.  Returns (final latents, timesteps used).  eta > 0
+    (pipeline/flex.py:247-251): `noise_fn(shape)` supplies the per-step variance noise.'''
     acp = ddim_ref.alphas_cumprod()
     ts = ddim_ref.timesteps(steps, steps_offset=steps_offset)
     used = []
@@ -41,7 +42,8 @@ def denoise(sd_unet, ucfg, embeds, uncond, latents, steps, guidance, steps_offse
     for t in ts[t_start:]:
         eps = noise_pred(sd_unet, ucfg, x, int(t), embeds.float(), uncond.float(), guidance)
         x = ddim_ref.ddim_step(eps, int(t), x, acp, steps,
-                               prediction_type=getattr(ucfg, 'prediction_type', 'epsilon'))
+                               prediction_type=getattr(ucfg, 'prediction_type', 'epsilon'), eta=eta,
+                               noise=noise_fn(tuple(x.shape)) if eta else None)
         used.append(int(t))
         if callback:
             callback(int(t), x)

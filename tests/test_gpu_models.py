@@ -374,6 +374,86 @@ def test_sd15_c2_headline_psnr(sd15, dev):
     assert out.images.shape == (1, size, size, 3)
     assert float(img_ref.std()) > 0.02, 'degenerate image: parity would be vacuous'
     assert p >= 40.0, p
+    # the bench runs batch 8 (CFG batch 16): other tile / split-K choices and the shared CFG prefix than
+    # batch 1.  Sample 0 of the batch-8 pass (bench.py's prompts and noise) against the same oracle latents.
+    import bench
+    from flexdiffuse_amd import dist as fdist
+    prompts = bench.synth_prompts(8)
+    assert prompts[0] == prompt
+    emb8 = g.embeds(prompt=prompts, guide=img, **C2['embeds_kw'])
+    noise8 = fdist.global_noise(8, (4, size // 8, size // 8), C2['noise_seed'])
+    assert torch.equal(noise8[:1], lat0)
+    pipe(guide=SimpleGuide(enc, pipe.unet, C2['guidance'], steps, emb8), init_size=(size, size), latents=noise8,
+         output_type='np')
+    p8 = pipeline_ref.psnr(pipe.last_images[:1].cpu(), img_ref)
+    print(f'SD1.5 c2 at batch 8, sample 0: latent rel err {relerr(pipe.last_latents[:1], lat_ref):.4f}, PSNR {p8:.1f} dB')
+    assert p8 >= 40.0, p8
+
+
+def _cached_oracle_psnr(name, dev, pipe, clip, tok, sds, vcfg):
+    '''Device path of sample 0 of BASELINE configs[3] / configs[4] against the CPU fp32 oracle's final latents
+    cached by tests/golden/make_c45_oracle.py (its 60 / 100 UNet forwards at 96x96 take 20-35 CPU-minutes);
+    the oracle's VAE decode runs here.'''
+    import hashlib
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_c45_oracle import CONFIGS, inputs
+    from flexdiffuse_amd import Guide, SimpleGuide
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from oracle import pipeline_ref
+    c = CONFIGS[name]
+    o = np.load(os.path.join(GOLDEN, f'{name}_oracle.npz'))
+    inp = inputs(name)
+    enc = CLIPEncoder(clip, tok)
+    embeds = Guide(clip, tok, device='cuda').embeds(prompt=inp['prompt'], guide=inp['guide'], **c['embeds_kw'])
+    emb_err = float((embeds.float().cpu() - torch.from_numpy(o['embeds'])).abs().max())
+    assert emb_err < 3e-2 * max(1.0, float(np.abs(o['embeds']).max())), emb_err
+    guide = SimpleGuide(enc, pipe.unet, c['guidance'], c['steps'], embeds)
+    if c['strength'] is not None:
+        assert hashlib.sha256(inp['noise'].numpy().tobytes()).digest() == o['noise_sha'].tobytes()
+        out = pipe(guide=guide, init_image=inp['init'], strength=c['strength'],
+                   generator=torch.Generator('cpu').manual_seed(c['gen_seed']), output_type='np')
+        want_t = [int(t) for t in pipe.scheduler.timesteps[int(o['t_start'][0]):]]
+    else:
+        assert hashlib.sha256(inp['lat0'].numpy().tobytes()).digest() == o['noise_sha'].tobytes()
+        out = pipe(guide=guide, init_size=(c['size'], c['size']), latents=inp['lat0'], output_type='np')
+        want_t = [int(t) for t in pipe.scheduler.timesteps]
+    assert [int(t) for t in o['timesteps']] == want_t
+    lat_ref = torch.from_numpy(o['latents'])
+    img_ref = pipeline_ref.decode_image(sds['vae'], vcfg, lat_ref)
+    p = pipeline_ref.psnr(pipe.last_images.cpu(), img_ref)
+    print(f'{name}: guided-embedding max err {emb_err:.4f}, latent rel err {relerr(pipe.last_latents, lat_ref):.4f}, '
+          f'PSNR {p:.1f} dB, image std {float(img_ref.std()):.3f}, {len(want_t)} UNet evaluations')
+    assert out.images.shape == (1, c['size'], c['size'], 3)
+    assert float(img_ref.std()) > 0.02, 'degenerate image: parity would be vacuous'
+    return p
+
+
+def test_sd15_c4_img2img_psnr(dev):
+    '''BASELINE configs[3] at batch 1: SD1.5 img2img + Linear image guidance, 768x768, 50 DDIM steps, strength
+    0.6 => the 30 evaluations of timesteps[20:] (reference pipeline/flex.py:181-221 init, :262-287 loop): VAE
+    encode -> posterior sample -> add_noise -> loop -> decode on the device vs the cached CPU oracle;
+    final-image PSNR >= 40 dB.'''
+    if not os.path.exists(os.path.join(GOLDEN, 'c4_oracle.npz')):
+        pytest.skip('tests/golden/c4_oracle.npz not generated (tests/golden/make_c45_oracle.py c4)')
+    from flexdiffuse_amd import build
+    sds = build.synthetic_state_dicts('sd15', seed=0)
+    pipe, clip, tok = build.build_models(sds, 'sd15', dev, vae_encoder=True)
+    p = _cached_oracle_psnr('c4', dev, pipe, clip, tok, sds, build.configs('sd15')[1])
+    assert p >= 40.0, p
+
+
+def test_sd21_c5_psnr(dev):
+    '''BASELINE configs[4] at batch 1: SD2.1-size UNet (v-prediction, head dim 64, linear projections, context
+    1024) + OpenCLIP ViT-H/14 guide, 768x768, 50 DDIM steps, CFG 8, Linear image guidance, vs the cached CPU
+    oracle (no reference behaviour exists for c5: the oracle is the target); final-image PSNR >= 40 dB.'''
+    if not os.path.exists(os.path.join(GOLDEN, 'c5_oracle.npz')):
+        pytest.skip('tests/golden/c5_oracle.npz not generated (tests/golden/make_c45_oracle.py c5)')
+    from flexdiffuse_amd import build
+    sds = build.synthetic_state_dicts('sd21', seed=0)
+    pipe, clip, tok = build.build_models(sds, 'sd21', dev, vae_encoder=False)
+    p = _cached_oracle_psnr('c5', dev, pipe, clip, tok, sds, build.configs('sd21')[1])
+    assert p >= 40.0, p
 
 
 def test_img2img_vs_oracle(mini, dev):
@@ -459,6 +539,83 @@ def test_runner_gen_recipe(dev):
     assert np.array_equal(np.asarray(imgs[1]), np.asarray(again[1]))
     assert not np.array_equal(np.asarray(imgs[0]), np.asarray(other[0]))
     assert r._set_seed(-5) == 0 and r._set_seed(2 ** 40) == 2147483647
+
+
+def test_runner_gen_vs_oracle(dev):
+    '''utils.Runner.gen against the oracle (reference utils.py:149-166: seed -> generator, Guide.embeds with
+    gen's own defaults, `samples` sequential pipeline calls on ONE generator stream): the oracle replays the
+    recipe -- CPU generator seeded with the clamped seed, one randn per batch, GuideRef.embeds,
+    pipeline_ref.denoise, decode -- and every returned PIL image must match at PSNR >= 40 dB.'''
+    from flexdiffuse_amd import Runner, build
+    from flexdiffuse_amd.tokenizer import SyntheticTokenizer
+    from oracle import guide_ref, pipeline_ref
+    from test_oracle_clip import synth_image
+    sds = build.synthetic_state_dicts('mini', seed=0)
+    sds = {k: {n: t.half().float() for n, t in sd.items()} for k, sd in sds.items()}
+    ucfg, vcfg, ccfg = build.configs('mini')
+    r = Runner(state_dicts=sds, preset='mini', device='cuda')
+    img = synth_image(20, 512, 512)
+    steps, samples, seed, hw = 4, 2, 2 ** 40, 64          # the seed is clamped to 2^31 - 1 (utils.py:78-83)
+    kw = dict(guide_clustered=0.0, guide_threshold_mult=0.25, guide_linear=(0.0, 0.5))
+    imgs, grid = r.gen(prompt='a photo of a turtle', guide=img, init_size=(hw, hw), steps=steps, samples=samples,
+                       seed=seed, guidance_scale=8, **kw)
+    assert len(imgs) == samples
+    tok = SyntheticTokenizer(vocab_size=ccfg.text.vocab_size, model_max_length=ccfg.text.max_position_embeddings)
+    g = guide_ref.GuideRef(sds['clip'], ccfg, tok)
+    embeds = g.embeds(prompt='a photo of a turtle', guide=img, guide_mode=0, **kw)     # gen's default guide_mode is 0
+    gen = torch.Generator('cpu').manual_seed(2147483647)
+    for k in range(samples):
+        lat0 = torch.randn((1, 4, hw // 8, hw // 8), generator=gen)
+        lat, _ = pipeline_ref.denoise(sds['unet'], ucfg, embeds, g.prompt(''), lat0, steps, 8.0)
+        want = (pipeline_ref.decode_image(sds['vae'], vcfg, lat) * 255).round() / 255
+        got = torch.from_numpy(np.asarray(imgs[k]).astype(np.float32) / 255).permute(2, 0, 1)[None]
+        p = pipeline_ref.psnr(got, want)
+        print(f'Runner.gen sample {k}: PSNR {p:.1f} dB vs the oracle recipe')
+        assert p >= 40.0, (k, p)
+    assert float((torch.from_numpy(np.asarray(imgs[0]).astype(np.float32)) -
+                  torch.from_numpy(np.asarray(imgs[1]).astype(np.float32))).abs().mean()) > 0.5   # different noise per batch
+
+
+def test_ddim_eta_step_and_loop_vs_oracle(mini, dev):
+    '''DDIM eta > 0 (the reference passes `eta` through to scheduler.step, pipeline/flex.py:247-251,280-285):
+    (a) one scheduler.step with eta = 0.5 and an explicit CPU generator vs ddim_ref with the same noise, on
+    epsilon- and v-prediction; (b) the whole loop at eta = 0.5 -- the generic guide.noise_pred + scheduler.step
+    path, variance noise from torch's global CPU generator as the reference's scheduler draws it -- vs the
+    oracle loop fed the same noise stream: PSNR >= 40 dB.'''
+    from flexdiffuse_amd import DDIMScheduler, SimpleGuide
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from oracle import clip_ref, ddim_ref, pipeline_ref
+    g = torch.Generator().manual_seed(4)
+    x, eps = torch.randn((2, 4, 8, 8), generator=g), torch.randn((2, 4, 8, 8), generator=g)
+    acp = ddim_ref.alphas_cumprod()
+    for pred in ('epsilon', 'v_prediction'):
+        sch = DDIMScheduler(prediction_type=pred)
+        sch.set_timesteps(10)
+        for t in (900, 400, 0):
+            got = sch.step(eps.to(dev), t, x.to(dev), eta=0.5, generator=torch.Generator('cpu').manual_seed(9)).prev_sample
+            z = torch.randn(x.shape, generator=torch.Generator('cpu').manual_seed(9))
+            want = ddim_ref.ddim_step(eps, t, x, acp, 10, prediction_type=pred, eta=0.5, noise=z)
+            det = ddim_ref.ddim_step(eps, t, x, acp, 10, prediction_type=pred)
+            assert float((got.cpu() - want).abs().max()) < 1e-4, (pred, t)
+            assert float((want - det).abs().max()) > 1e-2      # the noise term is really there
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = mini
+    enc = CLIPEncoder(clip, tok)
+    steps, hw, eta = 5, 64, 0.5
+    guide = SimpleGuide(enc, pipe.unet, 8.0, steps, enc.prompt('a photo of a turtle'))
+    torch.manual_seed(21)
+    pipe(guide=guide, init_size=(hw, hw), eta=eta, generator=torch.Generator('cpu').manual_seed(5), output_type='np')
+    emb = clip_ref.text_hidden(sds['clip'], ccfg, tok('a photo of a turtle').input_ids)
+    unc = clip_ref.text_hidden(sds['clip'], ccfg, tok('').input_ids)
+    lat0 = torch.randn((1, 4, hw // 8, hw // 8), generator=torch.Generator('cpu').manual_seed(5))
+    torch.manual_seed(21)
+    lat, used = pipeline_ref.denoise(sds['unet'], ucfg, emb, unc, lat0, steps, 8.0, eta=eta,
+                                     noise_fn=lambda shape: torch.randn(shape))
+    lat_det, _ = pipeline_ref.denoise(sds['unet'], ucfg, emb, unc, lat0, steps, 8.0)
+    assert used == [int(t) for t in pipe.scheduler.timesteps]
+    p = pipeline_ref.psnr(pipe.last_images.cpu(), pipeline_ref.decode_image(sds['vae'], vcfg, lat))
+    print(f'DDIM eta {eta}: PSNR {p:.1f} dB; latents moved {float((lat - lat_det).abs().max()):.3f} off the eta = 0 path')
+    assert float((lat - lat_det).abs().max()) > 0.05
+    assert p >= 40.0, p
 
 
 def test_hip_graph_replay_matches_eager(mini, dev):

@@ -33,3 +33,34 @@ def test_step_invariants():
     n = torch.randn_like(x)
     noisy = D.add_noise(x, n, 580, acp)
     assert torch.allclose(noisy, acp[580].sqrt() * x + (1 - acp[580]).sqrt() * n)
+
+
+def test_eta_step_known_answers():
+    '''eta > 0 (DDIM paper eq. 12 / 16; the reference forwards eta, pipeline/flex.py:247-251): eta = 0 and
+    noise = None is the deterministic update; for eta = 1 sigma_t^2 is the DDPM posterior variance
+    (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev); the marginal variance of x_{t-1} given x0 stays 1 - a_prev;
+    and the product scheduler's host coefficients are the same numbers.'''
+    from flexdiffuse_amd.scheduler import DDIMScheduler
+    acp = D.alphas_cumprod()
+    g = torch.Generator().manual_seed(1)
+    x, eps, z = (torch.randn(2, 4, 8, 8, generator=g) for _ in range(3))
+    t, n = 500, 50
+    a_t, a_p = acp[t], acp[t - 1000 // n]
+    det = D.ddim_step(eps, t, x, acp, n)
+    assert torch.equal(D.ddim_step(eps, t, x, acp, n, eta=0.0, noise=z), det)
+    for eta in (0.5, 1.0):
+        sigma = eta * (((1 - a_p) / (1 - a_t)) * (1 - a_t / a_p)).sqrt()
+        out = D.ddim_step(eps, t, x, acp, n, eta=eta, noise=z)
+        x0 = (x - (1 - a_t).sqrt() * eps) / a_t.sqrt()
+        assert torch.allclose(out, a_p.sqrt() * x0 + (1 - a_p - sigma ** 2).sqrt() * eps + sigma * z, atol=1e-6)
+        # direction^2 + sigma^2 == 1 - a_prev: the marginal q(x_{t-1} | x0) is preserved
+        assert abs(float((1 - a_p - sigma ** 2) + sigma ** 2 - (1 - a_p))) < 1e-7
+        sch = DDIMScheduler()
+        sch.set_timesteps(n)
+        c = sch.step_coefficients(t, eta)
+        assert abs(float(c[4]) - float(sigma)) < 1e-6 and abs(float(c[3]) - float((1 - a_p - sigma ** 2).sqrt())) < 1e-6
+    # v-prediction goes through the same variance term
+    v = D.ddim_step(eps, t, x, acp, n, prediction_type='v_prediction', eta=1.0, noise=z)
+    v0 = D.ddim_step(eps, t, x, acp, n, prediction_type='v_prediction', eta=1.0, noise=torch.zeros_like(z))
+    sigma1 = (((1 - a_p) / (1 - a_t)) * (1 - a_t / a_p)).sqrt()
+    assert torch.allclose(v - v0, sigma1 * z, atol=1e-6)

@@ -115,3 +115,27 @@ def test_from_pretrained_layout(tmp_path):
     assert torch.equal(ids, direct) and ids[0, -1] == vocab['!']
     with pytest.raises(FileNotFoundError):
         build.load_tokenizer(str(tmp_path / 'missing'))
+
+
+def test_basic_cleanup_mode_known_answers():
+    '''text_cleanup='basic': the slow CLIPTokenizer's no-ftfy path (BERT BasicTokenizer first) that the
+    reference's pinned transformers 4.21.1 runs -- control / NUL / U+FFFD characters dropped, every CJK
+    ideograph its own piece -- against known answers of the published algorithm; identical to the default
+    mode on prompts without such characters.'''
+    vocab, merges = toy_vocab()
+    fast, basic = CLIPBPETokenizer(vocab, merges), CLIPBPETokenizer(vocab, merges, text_cleanup='basic')
+    assert CLIPBPETokenizer._basic_clean('a\x00b\x07c\ufffdd') == 'abcd'
+    assert CLIPBPETokenizer._basic_clean('x\ty\u00a0z') == 'x y z'                 # tab and NBSP (Zs) are whitespace
+    assert CLIPBPETokenizer._basic_clean('tab\u200bzero') == 'tabzero'             # U+200B is category Cf
+    assert CLIPBPETokenizer._basic_clean('日本語x') == ' 日  本  語 x'
+    assert CLIPBPETokenizer._basic_clean('한국어') == '한국어'                          # Hangul is not in the CJK ranges
+    # one piece per ideograph instead of one for the run
+    assert basic.tokenize('日本語') == [t for ch in '日本語' for t in fast.tokenize(ch)]
+    assert fast.tokenize('日本語') != basic.tokenize('日本語')
+    assert basic.encode('a\x00b') == fast.encode('ab') != fast.encode('a\x00b')
+    for p in PROMPTS:
+        if all(not CLIPBPETokenizer._is_cjk(ord(c)) and (c in '\t\n\r' or not __import__('unicodedata').category(c).startswith('C'))
+               and c != '\ufffd' for c in p):
+            assert basic.encode(p) == fast.encode(p), p
+    with pytest.raises(ValueError):
+        CLIPBPETokenizer(vocab, merges, text_cleanup='ftfy')

@@ -1,4 +1,6 @@
-'''Error structure of fd_xattn_q_f16 against the two launches it replaces (per head, channel, row block).'''
+'''Error structure of fd_xattn_q_f16 against the two launches it replaces (per head, channel, 16-row block) and a
+host-side decode of the packed K / V^T images against the tensors they were packed from.  (This is how the mixed
+K=32 / K=16 MFMA chain problem was located: images and Q exact, denominators wrong in random 16-row blocks.)'''
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flexdiffuse_amd import ops
@@ -19,12 +21,6 @@ xd, kd, vtd = x.to(dev), k.to(dev), vt.to(dev)
 st = ops.ln_row_stats(xd)
 img = ops.xattn_pack_kv(kd, vtd, rep * B, L, heads, d)
 q = ops.gemm(xd, lw, ln_stats=st)
-if os.environ.get('FD_XATTN_DBG') == '1':
-    gq = ops.xattn_q(xd, lw, st, img, HW, L, heads, d, n_rep=rep)
-    e = (gq.float() - q.float()).abs().cpu()
-    print('Q err max', float(e.max()), 'per 16-col frag', [round(float(e[:, c:c+16].max()), 4) for c in range(0, 320, 16)])
-    print('Q per 16-row block (first 256):', [round(float(e[r:r+16].max()), 3) for r in range(0, 256, 16)])
-    sys.exit(0)
 got = ops.xattn_q(xd, lw, st, img, HW, L, heads, d, n_rep=rep).float().cpu()
 want = ops.attention(q, kd, vtd, B, heads, HW, L, d, q_prescaled=True).float().cpu()
 err = (got - want).abs()
