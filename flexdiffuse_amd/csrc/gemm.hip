@@ -105,6 +105,17 @@ __device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
 #endif
 }
 
+// A/B switch (compile time): FD_GEMM_NT_STORE=1 stores the lean epilogue's output rows with the non-temporal hint
+// (a streamed output should not evict the A / W panels its neighbours still re-read from L2), 2: GEGLU rows only.
+#ifndef FD_GEMM_NT_STORE
+#define FD_GEMM_NT_STORE 0
+#endif
+template <bool NT>
+__device__ __forceinline__ void epi_store16(half_t* p, u32x4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+    else *reinterpret_cast<u32x4*>(p) = v;
+}
+
 // Lean epilogue for the common case: a tile that lies completely inside [M][N], fp16 output with
 // 16-byte-aligned rows, bias / per-sample bias already staged in LDS by the main loop, activation
 // and residual fixed at COMPILE time.  The generic epilogue below handles every flag at run time
@@ -180,7 +191,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
                     unsigned x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
                     swap16(x0, y0);
                     swap16(x1, y1);
-                    *reinterpret_cast<u32x4*>(Crow + jp * 16 + pcol) = u32x4{x0, x1, y0, y1};
+                    epi_store16<FD_GEMM_NT_STORE != 0>(Crow + jp * 16 + pcol, u32x4{x0, x1, y0, y1});
                 } else {
                     *reinterpret_cast<half4*>(Crow + jp * 16 + fq * 4) = og[jp];
                 }
@@ -256,7 +267,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
                     unsigned x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
                     swap16(x0, y0);
                     swap16(x1, y1);
-                    *reinterpret_cast<u32x4*>(Crow + j * 16 + pcol) = u32x4{x0, x1, y0, y1};
+                    epi_store16<FD_GEMM_NT_STORE == 1>(Crow + j * 16 + pcol, u32x4{x0, x1, y0, y1});
                 } else {
                     *reinterpret_cast<half4*>(Crow + j * 16 + fq * 4) = oh[j];
                 }

@@ -160,7 +160,15 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM;
+    // XCD-aware tile order (workgroups round-robin over the 8 XCDs): each XCD takes a contiguous range of row
+    // tiles, i.e. whole samples, so a sample's 120 KB of K / V^T images is fetched into ONE XCD's L2 instead of
+    // all eight (PMC, round-robin order: 60.1 MB read per launch for 42 MB of hidden states + 2 MB of images)
+    int tile = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = tile & 7, slot = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int m0 = tile * BM;
     const int fr = lane & 15, fq = lane >> 4;
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, a_bytes, 0x00020000);

@@ -597,7 +597,8 @@ def test_ddim_eta_step_and_loop_vs_oracle(mini, dev):
             want = ddim_ref.ddim_step(eps, t, x, acp, 10, prediction_type=pred, eta=0.5, noise=z)
             det = ddim_ref.ddim_step(eps, t, x, acp, 10, prediction_type=pred)
             assert float((got.cpu() - want).abs().max()) < 1e-4, (pred, t)
-            assert float((want - det).abs().max()) > 1e-2      # the noise term is really there
+            if t > 0:       # the last step has a_prev = a_t: zero variance, eta changes nothing there
+                assert float((want - det).abs().max()) > 1e-2      # the noise term is really there
     sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = mini
     enc = CLIPEncoder(clip, tok)
     steps, hw, eta = 5, 64, 0.5
