@@ -485,8 +485,8 @@ def main():
         # HBM bytes of the dominant kernel (level-0 conv3x3) from its PMC pass: rocprofv3 cannot
         # run inside this process, so the committed per-launch measurement is reported with its
         # source (it is NOT re-measured by this run)
-        traffic, traffic_of = None, None
-        for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        traffic, traffic_of, traffic_other = None, None, None
+        for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', name)) as f:
                     tj = json.load(f)
@@ -494,6 +494,10 @@ def main():
                 traffic_of = (f"{tj['problem']}: {tj['hbm_bytes'] / 1e6:.1f} MB per launch vs "
                               f"{tj['algorithmic_bytes'] / 1e6:.1f} MB algorithmic; constant from "
                               f"profiles/{name} (commit {tj.get('commit', 'n/a')}), not measured in this run")
+                # HBM-side bytes per launch of the other kernels of that PMC set (same source, same caveat)
+                traffic_other = {k: {'hbm_bytes': v['hbm_bytes'], 'algorithmic_bytes': v['algorithmic_bytes'],
+                                     'over_algorithmic': v.get('traffic_over_algorithmic')}
+                                 for k, v in tj.get('other_kernels', {}).items()} or None
                 break
             except (OSError, KeyError, ValueError):
                 continue
@@ -534,6 +538,7 @@ def main():
                 'bound': 'mfma', 'kernel': 'k_gemm_f16 (implicit-GEMM conv3x3 / GEMM family)',
                 'achieved': achieved, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_of': traffic_of,
+                'traffic_other_kernels': traffic_other,
                 # sums over the sampled launches (every EVENT_STRIDE-th of each family) of one
                 # untimed pass, empty-bracket cost subtracted, scaled to the pass
                 'sampled_every': EVENT_STRIDE, 'sampled_launches': g['launches'],

@@ -59,7 +59,8 @@ struct GemmArgs {
     float* ln_stats_out;    // row statistics (rstd, -mean*rstd) of the OUTPUT rows, written by full-row tiles (N == BN)
     float ln_eps;
     const float* ln_stats;  // LayerNorm fold: per row of A (rstd, -mean*rstd); bias2 = column sums of W, bias = folded bias
-    int split_k;   // > 1: blockIdx.y owns a K slice and stores fp32 partials to `ws`
+    int split_k;   // > 1: a workgroup owns a K slice (blockIdx.y, or see sk_flat) and stores fp32 partials to `ws`
+    int sk_flat;   // split-K on a flat 1-D grid: slice = blockIdx.x % split_k, tile = blockIdx.x / split_k (see k_gemm_f16_dma)
     float* ws;     // [split_k][M][N] fp32
 };
 
@@ -305,7 +306,7 @@ template <int BM, int BN, bool TRANS, int WM = 2, int WN = 2, bool LN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                                               floatx4 (&acc)[BM / WM / 16][BN / WN / 16], int m0, int n0,
                                               int wm, int wn, int fr, int fq, int z,
-                                              lds_cfloat bias_tile = nullptr, lds_cfloat bias2_tile = nullptr) {
+                                              lds_cfloat bias_tile = nullptr, lds_cfloat bias2_tile = nullptr, int kslice = -1) {
     // bias_tile: this tile's bias[n0 .. n0+BN) staged in LDS by the main loop's first DMA group
     // (zeros past N).  A bias read from global memory here is a dependent L2 round trip that
     // every wave of the workgroup sits out between the last MFMA and the first store
@@ -320,7 +321,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
     constexpr int MI = WTM / 16, NI = WTN / 16;
     // ---- split-K: raw fp32 partial tile, reduced + finished by k_splitk_finish ------------
     if (g.split_k > 1) {
-        float* __restrict__ P = g.ws + (size_t)blockIdx.y * g.M * g.N;
+        float* __restrict__ P = g.ws + (size_t)(kslice >= 0 ? kslice : (int)blockIdx.y) * g.M * g.N;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + wm * WTM + i * 16 + fr;
@@ -794,7 +795,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     const int wm = wave / WN, wn = wave % WN;
     const int nb = g.tiles_m * g.tiles_n;
     int id = blockIdx.x;
-    {
+    int kslice = blockIdx.y;
+    if (g.sk_flat) {
+        // split-K on a flat grid: workgroups go round-robin over the 8 XCDs, so with slice = id % split_k every
+        // workgroup of one K slice (all m- and n-tiles) lands on the same XCD(s): that slice of W and of the
+        // gathered input is fetched into ONE L2 instead of up to eight (PMC, M 1024 N 1280 K 11520 split 8 with the
+        // 2-D grid: 125 MB read per launch for 53 MB of operands)
+        kslice = id % g.split_k;
+        id /= g.split_k;
+    } else {
         const int q = nb >> 3, r = nb & 7, xcd = id & 7, slot = id >> 3;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
@@ -865,7 +874,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     const int Hv = g.up ? g.Hi * 2 : g.Hi, Wv = g.up ? g.Wi * 2 : g.Wi;
     const int nk_all = (g.K + BK - 1) / BK;
     const int kt_per = (nk_all + g.split_k - 1) / g.split_k;
-    const int kt0 = blockIdx.y * kt_per;
+    const int kt0 = kslice * kt_per;
     const int nk = min(nk_all, kt0 + kt_per);
     const int ktail = g.K - ck * 8;
     int kh = 0, kw = 0, ci0 = 0;
@@ -1047,7 +1056,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
 #undef GEMM_DMA_TILE
     if constexpr (EPI == 0 || EPI == 7)   // 7: the generic epilogue with the LayerNorm fold compiled in
         gemm_epilogue<BM, BN, TRANS, WM, WN, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
-                                                       b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr);
+                                                       b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr, kslice);
     else if constexpr (EPI == 8 || EPI == 9)   // lean + LayerNorm statistics of the written rows (N == BN); the
         // exchange buffer reuses stage 0 (the K loop ended with a barrier: the stages are dead)
         gemm_epilogue_fast<MI, NI, FD_ACT_NONE, EPI == 9, true, false, true, WN>(
@@ -1398,8 +1407,14 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
                                    st, g, (unsigned)a_bytes, (unsigned)w_bytes);
             }
         } else {
+            static const int sk_flat = getenv("FD_GEMM_SK_FLAT") ? atoi(getenv("FD_GEMM_SK_FLAT")) : 1;
+            if (g.split_k > 1 && batch == 1 && sk_flat) {
+                g.sk_flat = 1;
+                grid = dim3(g.tiles_m * g.tiles_n * g.split_k, 1, 1);
+            }
             hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV, WM, TRANS, NS, WN, EPI>), grid, dim3(64 * WM * WN), lds, st, g,
                                (unsigned)a_bytes, (unsigned)w_bytes);
+            g.sk_flat = 0;
         }
         FD_CHECK_LAUNCH("k_gemm_f16_dma");
         return FD_OK;
