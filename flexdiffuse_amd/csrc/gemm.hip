@@ -1407,7 +1407,8 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
                                    st, g, (unsigned)a_bytes, (unsigned)w_bytes);
             }
         } else {
-            static const int sk_flat = getenv("FD_GEMM_SK_FLAT") ? atoi(getenv("FD_GEMM_SK_FLAT")) : 1;
+            // measured neutral (profiles/r03_session_ab.txt sec. 5): off by default, kept as an A/B knob
+            static const int sk_flat = getenv("FD_GEMM_SK_FLAT") ? atoi(getenv("FD_GEMM_SK_FLAT")) : 0;
             if (g.split_k > 1 && batch == 1 && sk_flat) {
                 g.sk_flat = 1;
                 grid = dim3(g.tiles_m * g.tiles_n * g.split_k, 1, 1);
