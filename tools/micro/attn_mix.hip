@@ -29,10 +29,10 @@ __device__ __forceinline__ half8 rnd8(unsigned seed) {
     return v;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(1024) void k(float* out, int iters) {
+template <int MODE, int NT = 1024, int SYNC = 0>
+__global__ __launch_bounds__(NT) void k(float* out, int iters) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned tid = blockIdx.x * 1024 + threadIdx.x;
+    const unsigned tid = blockIdx.x * NT + threadIdx.x;
     // few distinct fragment registers (the product kernel re-reads K / V^T fragments from LDS, they are transient there)
     half8 kf[4], qf[4], vf[3];
     for (int i = 0; i < 4; ++i) kf[i] = rnd8(tid * 31 + i);
@@ -44,6 +44,11 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters) {
     for (int d = 0; d < 2; ++d) for (int r = 0; r < 16; ++r) o32[d][r] = 0.f;
     float keep = 0.f;
     for (int it = 0; it < iters; ++it) {
+        // SYNC 1: one workgroup barrier per tile, as the product kernel has for its shared K / V^T stage: the waves of a
+        // workgroup then run every tile in the SAME phase (all in QK^T, all in the softmax, all in PV)
+        if (SYNC == 1) __syncthreads();
+        // SYNC 2: the same barrier, but the odd waves of each SIMD pair enter the loop half a tile late (their first
+        // iteration skips the QK^T + softmax half), so that a SIMD always has one wave in MFMAs while the other does VALU
         float sc[32];   // the 32 scores a lane owns per 64-key tile: 2 query blocks x 16, or 1 query column x 2 x 16
         if (MODE == 0 || MODE == 3) {
             floatx4 s[2][4];
@@ -140,17 +145,18 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters) {
 #endif
 }
 
-template <int MODE>
+template <int MODE, int NT = 1024, int SYNC = 0>
 void run(float* out, const char* what) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 4096;   // 64 tiles x 64 query-block passes: the order of one level-0 launch per wave
-    hipLaunchKernelGGL((k<MODE>), dim3(256), dim3(1024), 0, 0, out, 64);
+    const int grid = 256 * (1024 / NT);
+    hipLaunchKernelGGL((k<MODE, NT, SYNC>), dim3(grid), dim3(NT), 0, 0, out, 64);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<MODE>), dim3(256), dim3(1024), 0, 0, out, iters);
+    hipLaunchKernelGGL((k<MODE, NT, SYNC>), dim3(grid), dim3(NT), 0, 0, out, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("mode %d %-64s %8.3f ms  %7.1f ns / tile-iteration\n", MODE, what, ms, 1e6 * ms / iters);
+    printf("mode %d nt %4d sync %d %-64s %8.3f ms  %7.1f ns / tile-iteration\n", MODE, NT, SYNC, what, ms, 1e6 * ms / iters);
 }
 int main() {
     float* out; hipMalloc(&out, 256 * 1024 * 4);
@@ -161,6 +167,12 @@ int main() {
         run<3>(out, "MFMAs of mode 0 only");
         run<4>(out, "MFMAs of mode 1 only");
         run<5>(out, "softmax VALU only");
+        // does the per-tile workgroup barrier (lockstep phases) expose the softmax VALU?
+        run<0, 1024, 1>(out, "product mix, 16-wave workgroups, barrier per tile");
+        run<0, 512, 0>(out, "product mix, 2 x 8-wave workgroups per CU, no barrier");
+        run<0, 512, 1>(out, "product mix, 2 x 8-wave workgroups per CU, barrier per tile");
+        run<0, 256, 1>(out, "product mix, 4 x 4-wave workgroups per CU, barrier per tile");
+        run<3, 512, 1>(out, "MFMAs only, 2 x 8-wave workgroups per CU, barrier per tile");
     }
     return 0;
 }
