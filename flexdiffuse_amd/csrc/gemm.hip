@@ -60,6 +60,9 @@ struct GemmArgs {
     float ln_eps;
     const float* ln_stats;  // LayerNorm fold: per row of A (rstd, -mean*rstd); bias2 = column sums of W, bias = folded bias
     int split_k;   // > 1: a workgroup owns a K slice (blockIdx.y, or see sk_flat) and stores fp32 partials to `ws`
+    const half_t* A2;   // conv + appended 1x1 phase: after the conv's K-tiles the loop runs K2 more columns over the rows of
+    unsigned a2_bytes;
+    int lda2, K2;       // A2 [M][lda2] (the ResBlock's shortcut conv folded into conv2's accumulation); W is [N][K + K2]
     int sk_flat;   // split-K on a flat 1-D grid: slice = blockIdx.x % split_k, tile = blockIdx.x / split_k (see k_gemm_f16_dma)
     float* ws;     // [split_k][M][N] fp32
 };
@@ -376,7 +379,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
             half4 oh[MI];
             if (LN && g.ln_stats) {
                 // LayerNorm fold on the transposed layout (row statistics hoisted out of the n loop)
-                const float csn = (n_ok && g.bias2) ? g.bias2[n] : 0.f;
+                // column sum of the folded weights: from the LDS tile when the main loop staged it -- a global load
+                // here is waited for with vmcnt(0), i.e. together with the next tile's DMA, once per column fragment
+                const float csn = (n_ok && g.bias2) ? (bias2_tile ? bias2_tile[n - n0] : g.bias2[n]) : 0.f;
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -814,6 +819,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
         (void*)(g.A + (size_t)z * g.strideA), 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(g.W + (size_t)z * g.strideW), 0, w_bytes, 0x00020000);
+    // conv + appended 1x1 phase (the ResBlock shortcut accumulated by conv2's own K loop): rows of A2
+    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(CONV && g.K2 ? g.A2 : g.A), 0, CONV && g.K2 ? g.a2_bytes : 0u, 0x00020000);
     // this tile's bias -> LDS (4 B per lane, 64 columns per wave instruction; zeros past N),
     // ahead of the first K-tile so that it lands with it
     float* bias_s = reinterpret_cast<float*>(smem + NS * STAGE);
@@ -872,7 +880,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     const unsigned b_voff0 = (unsigned)((n0 + wave * 8 + rsub) * g.ldw + ck * 8) * 2u;
     const int b_group = NW * 8 * g.ldw * 2;   // bytes between a lane's consecutive W rows
     const int Hv = g.up ? g.Hi * 2 : g.Hi, Wv = g.up ? g.Wi * 2 : g.Wi;
-    const int nk_all = (g.K + BK - 1) / BK;
+    const int nkc = (g.K + BK - 1) / BK;                                  // K-tiles of the convolution / GEMM proper
+    const int nk_all = nkc + (CONV ? g.K2 / BK : 0);                      // + the appended 1x1 phase
     const int kt_per = (nk_all + g.split_k - 1) / g.split_k;
     const int kt0 = kslice * kt_per;
     const int nk = min(nk_all, kt0 + kt_per);
@@ -883,7 +892,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     // (the nine taps re-read the same input rows, so the re-use distance in the XCD's L2 drops
     // from Cin/64 K-tiles to one); the W K-offset follows, the sum is only re-ordered
     const int ntaps = CONV ? g.K / g.Cin : 1;
-    if (CONV && kt0 > 0) {
+    if (CONV && kt0 > 0 && kt0 < nkc) {
         if (g.tap_fast) {
             const int tap = kt0 % ntaps;
             ci0 = (kt0 / ntaps) * BK;
@@ -900,8 +909,22 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
 #define GEMM_DMA_TILE(KT, BUF)                                                              \
     {                                                                                       \
         char* stage = smem + (BUF) * STAGE;                                                 \
-        const int wko = CONV ? ((kh * g.KW + kw) * g.Cin + ci0) * 2 : (KT) * BK * 2;        \
-        if (CONV) {                                                                         \
+        int wko = CONV ? ((kh * g.KW + kw) * g.Cin + ci0) * 2 : (KT) * BK * 2;              \
+        if (CONV && (KT) >= nkc) { /* appended 1x1 phase: plain rows of A2, W columns continue after K */ \
+            if (new_tap) {                                                                  \
+                _Pragma("unroll") for (int i = 0; i < AR; ++i) {                            \
+                    const int m = m0 + (i * NW + wave) * 8 + rsub;                          \
+                    a_voff[i] = m < g.M ? (unsigned)(m * g.lda2 + ck * 8) * 2u : g.a2_bytes; \
+                }                                                                           \
+                new_tap = false;                                                            \
+            }                                                                               \
+            const int soff = ((KT) - nkc) * BK * 2;                                         \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i)                                  \
+                if (AG % NW == 0 || i * NW + wave < AG)                                     \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                   \
+                    rsA2, (lds_ptr)(stage + (i * NW + wave) * 1024), 16, a_voff[i], soff, 0, 0); \
+            wko = (g.K + ((KT) - nkc) * BK) * 2;                                            \
+        } else if (CONV) {                                                                  \
             if (new_tap) {                                                                  \
                 _Pragma("unroll") for (int i = 0; i < AR; ++i) {                            \
                     int iy = (int)(a_yx[i] >> 16) + kh - 16;                                \
@@ -1098,13 +1121,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
     int bias_par = 0;
     // EPI 5 / 6 (LayerNorm fold): the column sums of the folded weights (bias2, one row) ride along
     const __amdgpu_buffer_rsrc_t rsB2 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(((EPI == 5 || EPI == 6) && g.bias2) ? (const void*)g.bias2 : (const void*)g.W), 0,
-        ((EPI == 5 || EPI == 6) && g.bias2) ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
+        (void*)(((EPI == 5 || EPI == 6 || EPI == 7) && g.bias2) ? (const void*)g.bias2 : (const void*)g.W), 0,
+        ((EPI == 5 || EPI == 6 || EPI == 7) && g.bias2) ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
 #define GEMM_DMA_BIAS(PAR)                                                                  \
     if (wave * 64 + lane < BN) {                                                             \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(bias_s + (PAR) * BN + wave * 64), 4, \
                                                  (unsigned)(ld_n0 + wave * 64 + lane) * 4u, 0, 0, 0); \
-        if constexpr (EPI == 5 || EPI == 6)                                                  \
+        if constexpr (EPI == 5 || EPI == 6 || EPI == 7)                                      \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(bias_s + (2 + (PAR)) * BN + wave * 64), 4, \
                                                      (unsigned)(ld_n0 + wave * 64 + lane) * 4u, 0, 0, 0); \
     }
@@ -1280,7 +1303,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
         }
         if constexpr (EPI == 0 || EPI == 7)
             gemm_epilogue<BM, BN, TRANS, WM, WN, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z,
-                                                           (g.bias && g.bias_lds) ? (lds_cfloat)(bias_s + bias_par * BN) : (lds_cfloat) nullptr);
+                                                           (g.bias && g.bias_lds) ? (lds_cfloat)(bias_s + bias_par * BN) : (lds_cfloat) nullptr,
+                                                           (EPI == 7 && g.ln_stats && g.bias2) ? (lds_cfloat)(bias_s + (2 + bias_par) * BN) : (lds_cfloat) nullptr);
         else
             gemm_epilogue_fast<MI, NI, (EPI == 3 || EPI == 6) ? FD_ACT_GEGLU : FD_ACT_NONE, (EPI == 2 || EPI == 9), false, (EPI == 5 || EPI == 6)>(
                 g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z,
@@ -1378,7 +1402,7 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     const unsigned long long a_bytes =
         CONV ? 2ull * (g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi * g.Cin
              : 2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K);
-    const unsigned long long w_bytes = 2ull * ((unsigned long long)(g.N - 1) * g.ldw + g.K);
+    const unsigned long long w_bytes = 2ull * ((unsigned long long)(g.N - 1) * g.ldw + g.K + g.K2);
     if (g_use_dma && a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull) {
         static bool configured = false;
         if (!configured && lds > 64 * 1024) {
@@ -1394,7 +1418,7 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         const int occ = (BM >= 256 || lds > 80 * 1024) ? 1 : (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);  // workgroups / CU
         const int slots = 256 * occ;
         const int nkt = (g.K + BK - 1) / BK / g.split_k;
-        const bool persistent = NS == 2 && BN != 320 && (g_persist_mode == 2 ||
+        const bool persistent = NS == 2 && BN != 320 && g.K2 == 0 && (g_persist_mode == 2 ||
                                 (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots));
         if constexpr (EPI >= 1 && EPI <= 3) {
             // the persistent loop does not stage the per-sample bias: generic epilogue there
@@ -1422,6 +1446,10 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     }
     if (g.ln_stats) {
         fd_set_error("fd_gemm_f16: the LayerNorm fold needs the LDS-DMA path (tensor < 2 GiB, FD_GEMM_NO_DMA unset)");
+        return FD_ESHAPE;
+    }
+    if (g.K2) {
+        fd_set_error("fd_gemm_f16: the appended 1x1 phase (A2 / K2) needs the LDS-DMA path (tensor < 2 GiB, FD_GEMM_NO_DMA unset)");
         return FD_ESHAPE;
     }
     if constexpr (EPI != 0) {
@@ -1545,7 +1573,17 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         FD_CHECK_ARG(d->K == d->kh * d->kw * d->in_c, FD_EINVAL, "fd_gemm_f16: K != kh*kw*Cin");
         FD_CHECK_ARG(d->M % (d->out_h * d->out_w) == 0, FD_EINVAL,
                      "fd_gemm_f16: M is not a multiple of out_h*out_w");
+        if (d->K2 > 0) {
+            // appended 1x1 phase: C += A2 W[:, K:K+K2]^T inside the same K loop (a ResBlock's shortcut conv folded into conv2)
+            FD_CHECK_ARG(d->A2 && d->K2 % BK == 0 && d->lda2 % 8 == 0 && d->lda2 >= d->K2 && (uintptr_t)d->A2 % 16 == 0 &&
+                             d->ldw >= d->K + d->K2 && batch == 1 && !d->trans_out,
+                         FD_ESHAPE, "fd_gemm_f16: A2 / K2 need K2 %% 64 == 0, lda2 %% 8 == 0, ldw >= K + K2, 16-byte aligned A2");
+            const unsigned long long a2b = 2ull * ((unsigned long long)(d->M - 1) * d->lda2 + d->K2);
+            FD_CHECK_ARG(a2b < 0x7fffffffull, FD_ESHAPE, "fd_gemm_f16: A2 >= 2 GiB");
+            g.A2 = (const half_t*)d->A2; g.lda2 = d->lda2; g.K2 = d->K2; g.a2_bytes = (unsigned)a2b;
+        }
     } else {
+        FD_CHECK_ARG(d->K2 == 0, FD_EINVAL, "fd_gemm_f16: A2 / K2 only with conv != 0");
         FD_CHECK_ARG(d->lda % 8 == 0, FD_ESHAPE, "fd_gemm_f16: lda=%d must be a multiple of 8",
                      d->lda);
     }
@@ -1575,7 +1613,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         g.ldb2 = 0;
     }
     hipStream_t st = (hipStream_t)stream;
-    const double flops = 2.0 * (double)d->M * d->N * d->K * batch;
+    const double flops = 2.0 * (double)d->M * d->N * ((double)d->K + (d->conv ? d->K2 : 0)) * batch;
     g.split_k = 1;
     g.bias_lds = g_bias_lds;
     g.ws = (float*)d->workspace;
@@ -1604,7 +1642,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     //  * when the tile count cannot fill 2 workgroups on each of the 256 CUs, split K until it
     //    does (fp32 slabs + fixed-order finish kernel, so results stay deterministic).
     const bool geglu = g.act == FD_ACT_GEGLU;
-    const int nk_all = (g.K + BK - 1) / BK;
+    const int nk_all = (g.K + g.K2 + BK - 1) / BK;
     const bool n160 = (g.N % 160 == 0) && !geglu;
     const long long tiles_wide =
         (long long)fd_cdiv(g.M, 128) * (n160 ? fd_cdiv(g.N, 160) : fd_cdiv(g.N, 128)) * batch;

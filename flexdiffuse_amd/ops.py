@@ -32,7 +32,7 @@ class fd_gemm_desc(ctypes.Structure):
                 ('batch_stride_c', c_int64), ('batch_stride_res', c_int64),
                 ('tile', c_int32), ('split_k', c_int32), ('workspace', c_void_p),
                 ('workspace_bytes', c_int64), ('ln_stats', c_void_p), ('ln_colsum', c_void_p),
-                ('ln_stats_out', c_void_p), ('ln_eps', c_float)]
+                ('ln_stats_out', c_void_p), ('ln_eps', c_float), ('A2', c_void_p), ('lda2', c_int32), ('K2', c_int32)]
 
 
 class fd_attention_desc(ctypes.Structure):
@@ -74,6 +74,7 @@ class ConvW:
     kw: int
     im2col: bool                  # Cin < 64: explicit im2col + GEMM
     kpad: int
+    k2: int = 0                   # columns of an appended 1x1 shortcut (prep_conv_shortcut)
 
 
 def _bias(b: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
@@ -153,6 +154,22 @@ def prep_conv(w: torch.Tensor, b: Optional[torch.Tensor], dev, cin_pad: int = 0)
     wd = torch.zeros((cout, kpad), dtype=torch.float16, device=dev)
     wd[:, :k] = wp.reshape(cout, k).to(dev, torch.float16)
     return ConvW(wd, _bias(b, dev), cout, cin_eff, kh, kw, im2col, kpad)
+
+
+def prep_conv_shortcut(w: torch.Tensor, b: Optional[torch.Tensor], ws: torch.Tensor, bs: Optional[torch.Tensor],
+                       dev) -> ConvW:
+    '''conv (kh x kw) weights [Cout][Cin][kh][kw] with a 1x1 shortcut [Cout][Cx] appended along K:
+    [Cout][kh*kw*Cin | Cx] fp16, biases summed -- for conv2d(..., a2=x): the shortcut is accumulated by the
+    convolution's own K loop (fd_gemm_desc.A2 / K2).  Cin and Cx multiples of 64.'''
+    cout, cin, kh, kw = w.shape
+    cx = ws.shape[1]
+    assert cin % 64 == 0 and cx % 64 == 0 and ws.shape[0] == cout
+    k = kh * kw * cin
+    wd = torch.zeros((cout, k + cx), dtype=torch.float16, device=dev)
+    wd[:, :k] = w.permute(0, 2, 3, 1).reshape(cout, k).to(dev, torch.float16)
+    wd[:, k:] = ws.reshape(cout, cx).to(dev, torch.float16)
+    bias = (b.float() if b is not None else 0.0) + (bs.float() if bs is not None else 0.0)
+    return ConvW(wd, _bias(bias if torch.is_tensor(bias) else None, dev), cout, cin, kh, kw, False, k, cx)
 
 
 def f32(t: torch.Tensor, dev) -> torch.Tensor:
@@ -281,8 +298,10 @@ def bgemm(a: torch.Tensor, w: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
 def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), up: bool = False,
            out_hw: Optional[Tuple[int, int]] = None, act: int = ACT_NONE,
            residual: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None,
-           ld_bias2: int = 0, out_f32: bool = False, out: Optional[torch.Tensor] = None) -> Act:
-    '''NHWC conv (kh x kw) as implicit GEMM; `up` fuses a nearest-2x upsample of the input.'''
+           ld_bias2: int = 0, out_f32: bool = False, out: Optional[torch.Tensor] = None,
+           a2: Optional[torch.Tensor] = None) -> Act:
+    '''NHWC conv (kh x kw) as implicit GEMM; `up` fuses a nearest-2x upsample of the input.  `a2` [M][Cx]
+    (row stride free): the rows of the 1x1 shortcut appended to `w` by prep_conv_shortcut.'''
     assert x.C == w.cin, (x.C, w.cin)
     Hv, Wv = (x.H * 2, x.W * 2) if up else (x.H, x.W)
     if out_hw is None:
@@ -314,6 +333,12 @@ def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), 
         d.conv, d.in_h, d.in_w, d.in_c = 1, x.H, x.W, w.cin
         d.out_h, d.out_w, d.kh, d.kw = Ho, Wo, w.kh, w.kw
         d.stride, d.pad_t, d.pad_l, d.upsample2x = stride, pad[0], pad[1], int(up)
+    k2 = w.k2
+    if k2:
+        assert a2 is not None and not w.im2col and a2.shape == (M, k2) and a2.stride(1) == 1 and a2.dtype == torch.float16
+        d.A2, d.lda2, d.K2 = a2.data_ptr(), a2.stride(0), k2
+    else:
+        assert a2 is None
     _sched(d, x.t.device)
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     return Act(out, x.B, Ho, Wo)

@@ -30,10 +30,19 @@ class _Res:
         self.conv1 = ops.prep_conv(sd[name + '.conv1.weight'], sd[name + '.conv1.bias'], dev)
         self.conv2 = ops.prep_conv(sd[name + '.conv2.weight'], sd[name + '.conv2.bias'], dev)
         self.short = None
+        self.sc_fused = False
         if name + '.conv_shortcut.weight' in sd:
             w = sd[name + '.conv_shortcut.weight']
-            self.short = ops.prep_linear(w.reshape(w.shape[0], w.shape[1]),
-                                         sd[name + '.conv_shortcut.bias'], dev)
+            w2 = sd[name + '.conv2.weight']
+            if os.environ.get('FD_UNET_SC_FUSE', '1') != '0' and w.shape[1] % 64 == 0 and w2.shape[1] % 64 == 0:
+                # the 1x1 shortcut rides in conv2's own K loop (fd_gemm_desc.A2 / K2): no shortcut launch, no
+                # shortcut tensor written and re-read as conv2's residual
+                self.conv2 = ops.prep_conv_shortcut(w2, sd[name + '.conv2.bias'], w.reshape(w.shape[0], w.shape[1]),
+                                                    sd[name + '.conv_shortcut.bias'], dev)
+                self.sc_fused = True
+            else:
+                self.short = ops.prep_linear(w.reshape(w.shape[0], w.shape[1]),
+                                             sd[name + '.conv_shortcut.bias'], dev)
         self.cout = self.conv1.cout
         self.temb_off = temb_off  # column offset into the fused time-embedding projection
 
@@ -240,6 +249,8 @@ class UNet2DConditionModel():
         h = ops.conv2d(h, r.conv1, bias2=temb[:, r.temb_off:r.temb_off + r.cout],
                        ld_bias2=self.temb_total)
         h = ops.groupnorm(h, r.n2g, r.n2b, self.G, 1e-5, True)
+        if r.sc_fused:
+            return ops.conv2d(h, r.conv2, a2=x.t, out=out)
         sc = x.t if r.short is None else ops.gemm(x.t, r.short)
         return ops.conv2d(h, r.conv2, residual=sc, out=out)
 

@@ -32,7 +32,7 @@ extern "C" {
 #define FD_ESHAPE (-2) /* unsupported shape / alignment */
 #define FD_EHIP (-3)   /* HIP runtime error */
 
-#define FD_ABI_VERSION 6
+#define FD_ABI_VERSION 7
 
 int fd_abi_version(void);
 const char* fd_last_error(void);
@@ -186,6 +186,14 @@ typedef struct fd_gemm_desc {
      * tile spans the whole row: N == 320, M % 256 == 0, linear, plain or residual epilogue. NULL = off. */
     float* ln_stats_out;
     float ln_eps;
+    /* Convolution with an APPENDED 1x1 phase (conv != 0 only): after the K = kh*kw*in_c columns of the convolution the
+     * same K loop runs K2 more columns over the plain rows of A2 [M][lda2] against W[:, K .. K+K2), i.e.
+     *   C = epilogue( conv(A, W[:, :K]) + A2 W[:, K:]^T ).
+     * Folds a ResBlock's 1x1 shortcut convolution (diffusers ResnetBlock2D.conv_shortcut inside `unet(...)`, reference
+     * pipeline/guide.py:56-58) into conv2's accumulation: no separate shortcut launch, no shortcut tensor written and
+     * re-read as the residual.  W is [N][ldw] with ldw >= K + K2; K2 % 64 == 0; bias = both layers' biases summed. */
+    const void* A2;
+    int32_t lda2, K2;
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);

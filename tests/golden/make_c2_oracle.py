@@ -13,7 +13,10 @@ the 100 fp32 UNet forwards (~13 min on 8 cores) are not repeated on every GPU bo
 The oracle is `parity unpinned` for the UNet / VAE / DDIM part (diffusers 0.3.0 is absent,
 oracle/__init__.py); this file pins nothing new, it only caches the oracle's own output.
 
-Usage:  python tests/golden/make_c2_oracle.py [--steps 50] [--size 512]
+`--guidance clustered_threshold` writes c3_oracle.npz: the same sample under BASELINE configs[2]'s guidance
+parameters (Clustered 0.25 + Threshold (0.75, 0.25), linear off, max 0.35, header cap 0: bench.py GUIDANCE).
+
+Usage:  python tests/golden/make_c2_oracle.py [--steps 50] [--size 512] [--guidance linear|clustered_threshold]
 '''
 import argparse
 import hashlib
@@ -47,8 +50,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--out', default=os.path.join(HERE, 'c2_oracle.npz'))
+    ap.add_argument('--guidance', default='linear', choices=['linear', 'clustered_threshold'])
+    ap.add_argument('--out', default=None)
+    ap.add_argument('--threads', type=int, default=0)
     args = ap.parse_args()
+    if args.threads:
+        torch.set_num_threads(args.threads)
+    import bench
+    embeds_kw = C2['embeds_kw'] if args.guidance == 'linear' else bench.GUIDANCE[args.guidance]
+    if args.out is None:
+        args.out = os.path.join(HERE, 'c2_oracle.npz' if args.guidance == 'linear' else 'c3_oracle.npz')
     from flexdiffuse_amd import build
     from flexdiffuse_amd.tokenizer import SyntheticTokenizer
     from oracle import guide_ref, pipeline_ref
@@ -59,7 +70,7 @@ def main():
     prompt, img, lat0 = c2_inputs(args.size)
     t0 = time.time()
     g = guide_ref.GuideRef(sds['clip'], ccfg, tok)
-    embeds = g.embeds(prompt=prompt, guide=img, **C2['embeds_kw'])
+    embeds = g.embeds(prompt=prompt, guide=img, **embeds_kw)
     text = g.prompt(prompt)
     uncond = g.prompt('')
     t_embed = time.time() - t0

@@ -495,3 +495,39 @@ def test_fused_q_projection_cross_attention(dev, B, HW, rep, L):
         assert float((got[:M] - got[M:]).abs().max()) > 0.05
     assert not ops.xattn_supported(8, 80, L, HW) and not ops.xattn_supported(heads, d, 64, HW)
     assert not ops.xattn_supported(heads, d, L, 64)
+
+
+@pytest.mark.parametrize('B,H,Cin,Cx', [(16, 64, 320, 640), (4, 32, 640, 960), (16, 16, 1280, 2560), (16, 8, 1280, 2560),
+                                        (2, 16, 64, 128)])
+def test_conv_with_appended_shortcut(dev, B, H, Cin, Cx):
+    '''fd_gemm_desc.A2 / K2: a ResBlock's 1x1 shortcut accumulated by conv2's own K loop,
+    conv3x3(h) + x Ws^T + (b + bs), vs (a) a torch fp32 reference and (b) the two launches it replaces (shortcut GEMM,
+    then the conv with that tensor as residual: there the shortcut is rounded to fp16 once more, so (b) is a few
+    ulps).  Shapes: the 256x320 tap-fastest tile (level 0), 256x160 (level 1), split-K 2/4 (16x16) and 8 (8x8), a
+    small generic one.'''
+    from flexdiffuse_amd import ops
+    Cout = Cin
+    g = torch.Generator().manual_seed(B * H + Cx)
+    hx = (torch.randn((B, Cin, H, H), generator=g) * 0.7).half()
+    x = (torch.randn((B, Cx, H, H), generator=g) * 0.7).half()
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) * (9 * Cin) ** -0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ws = torch.randn((Cout, Cx), generator=g) * Cx ** -0.5
+    bs = torch.randn(Cout, generator=g) * 0.1
+    M = B * H * H
+    hd = ops.Act(hx.permute(0, 2, 3, 1).reshape(M, Cin).contiguous().to(dev), B, H, H)
+    # x as a column slice of a wider buffer (the decoder's concat buffers): row stride != Cx
+    xbuf = torch.zeros((M, Cx + 64), dtype=torch.float16, device=dev)
+    xbuf[:, :Cx] = x.permute(0, 2, 3, 1).reshape(M, Cx).to(dev)
+    xd = xbuf[:, :Cx]
+    fused = ops.conv2d(hd, ops.prep_conv_shortcut(w, b, ws, bs, dev), a2=xd).t.float().cpu()
+    want = F.conv2d(hx.float(), w.half().float(), b + bs, padding=1) + \
+        torch.einsum('bchw,oc->bohw', x.float(), ws.half().float())
+    want = want.permute(0, 2, 3, 1).reshape(M, Cout)
+    assert float((fused - want).abs().max()) <= 4e-3 * float(want.abs().max()) + 2e-3
+    sc = ops.gemm(xd, ops.prep_linear(ws, bs, dev))
+    two = ops.conv2d(hd, ops.prep_conv(w, b, dev), residual=sc).t.float().cpu()
+    assert float((fused - two).abs().max()) <= 4e-3 * float(want.abs().max()) + 2e-3
+    assert float((fused - want).abs().mean()) <= float((two - want).abs().mean()) * 1.05 + 1e-5   # one rounding fewer
+    with pytest.raises(AssertionError):
+        ops.conv2d(hd, ops.prep_conv_shortcut(w, b, ws, bs, dev))          # a2 missing

@@ -390,6 +390,40 @@ def test_sd15_c2_headline_psnr(sd15, dev):
     assert p8 >= 40.0, p8
 
 
+def test_sd15_c3_clustered_threshold_psnr(sd15, dev):
+    '''BASELINE configs[2] guidance (Clustered 0.25 + Threshold (0.75, 0.25), linear off, max 0.35, header cap 0) on
+    sample 0 of the headline workload: device path vs the cached CPU oracle of the same sample
+    (tests/golden/c3_oracle.npz, `make_c2_oracle.py --guidance clustered_threshold`); PSNR >= 40 dB.'''
+    path = os.path.join(GOLDEN, 'c3_oracle.npz')
+    if not os.path.exists(path):
+        pytest.skip('tests/golden/c3_oracle.npz not generated')
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import bench
+    from make_c2_oracle import C2, c2_inputs
+    from flexdiffuse_amd import Guide, SimpleGuide
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from oracle import pipeline_ref
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = sd15
+    o = np.load(path)
+    steps, size = int(o['steps'][0]), int(o['size'][0])
+    prompt, img, lat0 = c2_inputs(size)
+    embeds = Guide(clip, tok, device='cuda').embeds(prompt=prompt, guide=img, **bench.GUIDANCE['clustered_threshold'])
+    emb_ref = torch.from_numpy(o['embeds'])
+    emb_err = float((embeds.float().cpu() - emb_ref).abs().max())
+    moved = float((emb_ref - torch.from_numpy(o['text'])).abs().max())
+    assert moved > 0.05, 'the oracle guidance changed nothing: parity would be vacuous'
+    assert emb_err < 3e-2 * max(1.0, float(emb_ref.abs().max())), emb_err
+    out = pipe(guide=SimpleGuide(CLIPEncoder(clip, tok), pipe.unet, C2['guidance'], steps, embeds),
+               init_size=(size, size), latents=lat0, output_type='np')
+    assert [int(t) for t in o['timesteps']] == [int(t) for t in pipe.scheduler.timesteps]
+    lat_ref = torch.from_numpy(o['latents'])
+    p = pipeline_ref.psnr(pipe.last_images.cpu(), pipeline_ref.decode_image(sds['vae'], vcfg, lat_ref))
+    print(f'SD1.5 c3 guidance (Clustered + Threshold): guided-embedding max err {emb_err:.4f} (text moved {moved:.3f}), '
+          f'latent rel err {relerr(pipe.last_latents, lat_ref):.4f}, PSNR {p:.1f} dB')
+    assert out.images.shape == (1, size, size, 3) and p >= 40.0, p
+
+
 def _cached_oracle_psnr(name, dev, pipe, clip, tok, sds, vcfg):
     '''Device path of sample 0 of BASELINE configs[3] / configs[4] against the CPU fp32 oracle's final latents
     cached by tests/golden/make_c45_oracle.py (its 60 / 100 UNet forwards at 96x96 take 20-35 CPU-minutes);
