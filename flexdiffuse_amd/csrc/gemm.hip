@@ -819,9 +819,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
         (void*)(g.A + (size_t)z * g.strideA), 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(g.W + (size_t)z * g.strideW), 0, w_bytes, 0x00020000);
-    // conv + appended 1x1 phase (the ResBlock shortcut accumulated by conv2's own K loop): rows of A2
+    // appended phase (a second operand accumulated by the same K loop: the ResBlock shortcut in conv2, the
+    // transformer's proj_out folded through its feed-forward output GEMM): rows of A2
     const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(CONV && g.K2 ? g.A2 : g.A), 0, CONV && g.K2 ? g.a2_bytes : 0u, 0x00020000);
+        (void*)(g.K2 ? g.A2 : g.A), 0, g.K2 ? g.a2_bytes : 0u, 0x00020000);
     // this tile's bias -> LDS (4 B per lane, 64 columns per wave instruction; zeros past N),
     // ahead of the first K-tile so that it lands with it
     float* bias_s = reinterpret_cast<float*>(smem + NS * STAGE);
@@ -881,11 +882,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     const int b_group = NW * 8 * g.ldw * 2;   // bytes between a lane's consecutive W rows
     const int Hv = g.up ? g.Hi * 2 : g.Hi, Wv = g.up ? g.Wi * 2 : g.Wi;
     const int nkc = (g.K + BK - 1) / BK;                                  // K-tiles of the convolution / GEMM proper
-    const int nk_all = nkc + (CONV ? g.K2 / BK : 0);                      // + the appended 1x1 phase
+    const int nk_all = nkc + g.K2 / BK;                                   // + the appended phase over A2
     const int kt_per = (nk_all + g.split_k - 1) / g.split_k;
     const int kt0 = kslice * kt_per;
     const int nk = min(nk_all, kt0 + kt_per);
-    const int ktail = g.K - ck * 8;
+    const int ktail = g.K + g.K2 - ck * 8;   // (with an appended phase K and K2 are multiples of 64: no tail)
     int kh = 0, kw = 0, ci0 = 0;
     bool new_tap = true;
     // tap_fast: K-tiles visit all filter taps of one 64-channel slice before the next slice
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     {                                                                                       \
         char* stage = smem + (BUF) * STAGE;                                                 \
         int wko = CONV ? ((kh * g.KW + kw) * g.Cin + ci0) * 2 : (KT) * BK * 2;              \
-        if (CONV && (KT) >= nkc) { /* appended 1x1 phase: plain rows of A2, W columns continue after K */ \
+        if (g.K2 && (KT) >= nkc) { /* appended phase: plain rows of A2, W columns continue after K */ \
             if (new_tap) {                                                                  \
                 _Pragma("unroll") for (int i = 0; i < AR; ++i) {                            \
                     const int m = m0 + (i * NW + wave) * 8 + rsub;                          \
@@ -1573,19 +1574,19 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         FD_CHECK_ARG(d->K == d->kh * d->kw * d->in_c, FD_EINVAL, "fd_gemm_f16: K != kh*kw*Cin");
         FD_CHECK_ARG(d->M % (d->out_h * d->out_w) == 0, FD_EINVAL,
                      "fd_gemm_f16: M is not a multiple of out_h*out_w");
-        if (d->K2 > 0) {
-            // appended 1x1 phase: C += A2 W[:, K:K+K2]^T inside the same K loop (a ResBlock's shortcut conv folded into conv2)
-            FD_CHECK_ARG(d->A2 && d->K2 % BK == 0 && d->lda2 % 8 == 0 && d->lda2 >= d->K2 && (uintptr_t)d->A2 % 16 == 0 &&
-                             d->ldw >= d->K + d->K2 && batch == 1 && !d->trans_out,
-                         FD_ESHAPE, "fd_gemm_f16: A2 / K2 need K2 %% 64 == 0, lda2 %% 8 == 0, ldw >= K + K2, 16-byte aligned A2");
-            const unsigned long long a2b = 2ull * ((unsigned long long)(d->M - 1) * d->lda2 + d->K2);
-            FD_CHECK_ARG(a2b < 0x7fffffffull, FD_ESHAPE, "fd_gemm_f16: A2 >= 2 GiB");
-            g.A2 = (const half_t*)d->A2; g.lda2 = d->lda2; g.K2 = d->K2; g.a2_bytes = (unsigned)a2b;
-        }
     } else {
-        FD_CHECK_ARG(d->K2 == 0, FD_EINVAL, "fd_gemm_f16: A2 / K2 only with conv != 0");
         FD_CHECK_ARG(d->lda % 8 == 0, FD_ESHAPE, "fd_gemm_f16: lda=%d must be a multiple of 8",
                      d->lda);
+    }
+    if (d->K2 > 0) {
+        // appended phase: C += A2 W[:, K:K+K2]^T inside the same K loop
+        FD_CHECK_ARG(d->A2 && d->K2 % BK == 0 && d->K % BK == 0 && d->lda2 % 8 == 0 && d->lda2 >= d->K2 &&
+                         (uintptr_t)d->A2 % 16 == 0 && d->ldw >= d->K + d->K2 && batch == 1 && !d->trans_out && !d->ln_stats,
+                     FD_ESHAPE, "fd_gemm_f16: A2 / K2 need K %% 64 == 0, K2 %% 64 == 0, lda2 %% 8 == 0, ldw >= K + K2, "
+                                "16-byte aligned A2, no batch / transposed store / LayerNorm fold");
+        const unsigned long long a2b = 2ull * ((unsigned long long)(d->M - 1) * d->lda2 + d->K2);
+        FD_CHECK_ARG(a2b < 0x7fffffffull, FD_ESHAPE, "fd_gemm_f16: A2 >= 2 GiB");
+        g.A2 = (const half_t*)d->A2; g.lda2 = d->lda2; g.K2 = d->K2; g.a2_bytes = (unsigned)a2b;
     }
     if (g.act == FD_ACT_GEGLU)
         FD_CHECK_ARG(d->N % 32 == 0 && !d->trans_out && !d->out_f32 && !d->residual, FD_ESHAPE,
@@ -1613,7 +1614,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         g.ldb2 = 0;
     }
     hipStream_t st = (hipStream_t)stream;
-    const double flops = 2.0 * (double)d->M * d->N * ((double)d->K + (d->conv ? d->K2 : 0)) * batch;
+    const double flops = 2.0 * (double)d->M * d->N * ((double)d->K + d->K2) * batch;
     g.split_k = 1;
     g.bias_lds = g_bias_lds;
     g.ws = (float*)d->workspace;

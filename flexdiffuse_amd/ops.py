@@ -224,10 +224,13 @@ def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[to
          bias2: Optional[torch.Tensor] = None, ld_bias2: int = 0, rows_per_sample: int = 0,
          out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0,
          use_bias: bool = True, ln_stats: Optional[torch.Tensor] = None,
-         ln_stats_out: Optional[torch.Tensor] = None, ln_eps: float = 1e-5) -> torch.Tensor:
-    '''a [M][K] fp16 @ w[N][K]^T with fused epilogue -> [M][N] (GEGLU: [M][N/2]).'''
+         ln_stats_out: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
+         a2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    '''a [M][K] fp16 @ w[N][K]^T with fused epilogue -> [M][N] (GEGLU: [M][N/2]).  `a2` [M][K2]: a second operand
+    accumulated by the same K loop against w[:, K:K+K2] (fd_gemm_desc.A2 / K2; `w` holds K + K2 columns).'''
     M, K = a.shape
-    assert a.dtype == torch.float16 and a.stride(1) == 1 and K == w.K, (a.shape, w.K)
+    K2 = 0 if a2 is None else a2.shape[1]
+    assert a.dtype == torch.float16 and a.stride(1) == 1 and K + K2 == w.K, (a.shape, K2, w.K)
     n_out = w.N // 2 if act == ACT_GEGLU else w.N
     if out is None:
         out = _empty((M, _round_up(n_out, 4)), torch.float32 if out_f32 else torch.float16, a)
@@ -243,6 +246,9 @@ def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[to
     d.rows_per_sample = rows_per_sample
     d.act, d.out_f32, d.alpha = act, int(out_f32), alpha
     d.batch = 1
+    if a2 is not None:
+        assert a2.shape[0] == M and a2.stride(1) == 1 and a2.dtype == torch.float16
+        d.A2, d.lda2, d.K2 = a2.data_ptr(), a2.stride(0), K2
     if ln_stats is not None:      # `a` holds the un-normalised rows, `w` comes from prep_linear_ln
         assert w.colsum is not None and ln_stats.shape == (M, 2)
         d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), w.colsum.data_ptr()

@@ -93,6 +93,15 @@ class _Attn:
         self.o2 = ops.prep_linear(g(f'{tb}.attn2.to_out.0.weight'), g(f'{tb}.attn2.to_out.0.bias'), dev)
         self.ff2 = ops.prep_linear(g(f'{tb}.ff.net.2.weight'), g(f'{tb}.ff.net.2.bias'), dev)
         self.C = self.q2.N
+        # proj_out folded THROUGH the feed-forward output layer: proj_out(ff2(f) + h) = f (Wp W2)^T + h Wp^T + (bp + Wp b2)
+        # -- one GEMM over [f | h] (fd_gemm_desc.A2 / K2) instead of two, the block's last hidden state never
+        # goes to HBM.  Weight product in fp32, rounded to fp16 once.  FD_UNET_FF_FOLD=0: the two launches (A/B).
+        self.ffp = None
+        wp = g('.proj_out.weight')
+        wp = wp.reshape(wp.shape[0], wp.shape[1]).float()
+        w2, b2 = g(f'{tb}.ff.net.2.weight').float(), g(f'{tb}.ff.net.2.bias').float()
+        if os.environ.get('FD_UNET_FF_FOLD', '1') != '0' and w2.shape[1] % 64 == 0 and wp.shape[1] % 64 == 0:
+            self.ffp = ops.prep_linear(torch.cat([wp @ w2, wp], 1), g('.proj_out.bias').float() + wp @ b2, dev)
         self.ctx_kv = None  # (K [Be*L][C], V^T [Be][C][ldv]) of the cached text context
         self.ctx_img = None  # the same context packed for the fused q-projection + cross-attention kernel
 
@@ -307,6 +316,8 @@ class UNet2DConditionModel():
             f = ops.gemm(h, a.ff1, act=ops.ACT_GEGLU, ln_stats=st if st is not None else ops.ln_row_stats(h))
         else:
             f = ops.gemm(ops.layernorm(h, *a.ln[2]), a.ff1, act=ops.ACT_GEGLU)
+        if a.ffp is not None:
+            return Act(ops.gemm(f, a.ffp, a2=h, residual=xt, out=out), B, x.H, x.W)
         h = ops.gemm(f, a.ff2, residual=h)
         return Act(ops.gemm(h, a.proj_out, residual=xt, out=out), B, x.H, x.W)
 

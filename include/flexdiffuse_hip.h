@@ -186,12 +186,14 @@ typedef struct fd_gemm_desc {
      * tile spans the whole row: N == 320, M % 256 == 0, linear, plain or residual epilogue. NULL = off. */
     float* ln_stats_out;
     float ln_eps;
-    /* Convolution with an APPENDED 1x1 phase (conv != 0 only): after the K = kh*kw*in_c columns of the convolution the
-     * same K loop runs K2 more columns over the plain rows of A2 [M][lda2] against W[:, K .. K+K2), i.e.
-     *   C = epilogue( conv(A, W[:, :K]) + A2 W[:, K:]^T ).
-     * Folds a ResBlock's 1x1 shortcut convolution (diffusers ResnetBlock2D.conv_shortcut inside `unet(...)`, reference
-     * pipeline/guide.py:56-58) into conv2's accumulation: no separate shortcut launch, no shortcut tensor written and
-     * re-read as the residual.  W is [N][ldw] with ldw >= K + K2; K2 % 64 == 0; bias = both layers' biases summed. */
+    /* APPENDED phase: after the K columns of the GEMM / convolution the same K loop runs K2 more columns over the plain
+     * rows of a second operand A2 [M][lda2] against W[:, K .. K+K2):
+     *   C = epilogue( A-part(A, W[:, :K]) + A2 W[:, K:]^T ).
+     * Two uses inside `unet(...)` (reference pipeline/guide.py:56-58), both weight folds done once at model construction:
+     * a ResBlock's 1x1 shortcut convolution rides in conv2's accumulation (diffusers ResnetBlock2D.conv_shortcut: no
+     * shortcut launch, no shortcut tensor written and re-read as the residual); and a transformer block's proj_out is
+     * folded THROUGH the feed-forward output layer, proj_out(ff2(f) + h) = f (Wp W2)^T + h Wp^T + (bp + Wp b2): one GEMM
+     * with A = f, A2 = h instead of two.  W is [N][ldw] with ldw >= K + K2; K % 64 == 0, K2 % 64 == 0; LDS-DMA path only. */
     const void* A2;
     int32_t lda2, K2;
 } fd_gemm_desc;

@@ -531,3 +531,28 @@ def test_conv_with_appended_shortcut(dev, B, H, Cin, Cx):
     assert float((fused - want).abs().mean()) <= float((two - want).abs().mean()) * 1.05 + 1e-5   # one rounding fewer
     with pytest.raises(AssertionError):
         ops.conv2d(hd, ops.prep_conv_shortcut(w, b, ws, bs, dev))          # a2 missing
+
+
+@pytest.mark.parametrize('M,C', [(65536, 320), (16384, 640), (4096, 1280), (1024, 1280), (256, 64)])
+def test_gemm_with_appended_operand_folds_two_linears(dev, M, C):
+    '''fd_gemm_desc.A2 / K2 on a linear GEMM: out = f Wc^T + h Wp^T + b + residual in ONE K loop, the form the UNet
+    uses to fold proj_out through the feed-forward output layer (Wc = Wp W2): vs a torch fp32 reference of
+    proj_out(ff2(f) + h) + x and vs the two device launches it replaces.'''
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    f = (torch.randn((M, 4 * C), generator=g) * 0.5).half()
+    h = torch.randn((M, C), generator=g).half()
+    xr = torch.randn((M, C), generator=g).half()
+    w2, b2 = torch.randn((C, 4 * C), generator=g) * (4 * C) ** -0.5, torch.randn(C, generator=g) * 0.1
+    wp, bp = torch.randn((C, C), generator=g) * C ** -0.5, torch.randn(C, generator=g) * 0.1
+    want = ((f.float() @ w2.T + b2 + h.float()) @ wp.T + bp + xr.float())
+    lw = ops.prep_linear(torch.cat([wp @ w2, wp], 1), bp + wp @ b2, dev)
+    fd, hd, xd = f.to(dev), h.to(dev), xr.to(dev)
+    got = ops.gemm(fd, lw, a2=hd, residual=xd).float().cpu()
+    assert float((got - want).abs().max()) <= 6e-3 * float(want.abs().max()) + 2e-3
+    h2 = ops.gemm(fd, ops.prep_linear(w2, b2, dev), residual=hd)
+    two = ops.gemm(h2, ops.prep_linear(wp, bp, dev), residual=xd).float().cpu()
+    assert float((got - two).abs().max()) <= 8e-3 * float(want.abs().max()) + 2e-3
+    assert float((got - want).abs().mean()) <= float((two - want).abs().mean()) * 1.1 + 1e-5
+    with pytest.raises(AssertionError):
+        ops.gemm(fd, lw, residual=xd)      # K mismatch without the second operand
