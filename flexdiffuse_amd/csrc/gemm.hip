@@ -60,6 +60,7 @@ struct GemmArgs {
     float ln_eps;
     const float* ln_stats;  // LayerNorm fold: per row of A (rstd, -mean*rstd); bias2 = column sums of W, bias = folded bias
     int split_k;   // > 1: a workgroup owns a K slice (blockIdx.y, or see sk_flat) and stores fp32 partials to `ws`
+    int phase;          // phase-decomposed nearest-2x upsample + 3x3 conv: blockIdx.z = output-pixel parity (py, px), see fd_gemm_desc.upsample2x == 2
     const half_t* A2;   // conv + appended 1x1 phase: after the conv's K-tiles the loop runs K2 more columns over the rows of
     unsigned a2_bytes;
     int lda2, K2;       // A2 [M][lda2] (the ResBlock's shortcut conv folded into conv2's accumulation); W is [N][K + K2]
@@ -215,6 +216,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
             else if constexpr (B2) bb[j] += *reinterpret_cast<lds_cf4>(bias2_tile + coll + j * 16 + fq * 4);
         }
         half_t* Cb = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC + (size_t)row0 * g.ldc + col0;
+        if (g.phase) Cb = reinterpret_cast<half_t*>(g.C) + col0;   // rows are mapped per 16-row block below
         const half_t* Rb = RES ? g.res + (size_t)z * g.strideRes + (size_t)row0 * g.ldr + col0 + fq * 4 : nullptr;
         floatx2 st_next = {g.alpha, 0.f};   // LNF: one row block ahead (see the GEGLU branch)
         if constexpr (LNF) st_next = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)row0);
@@ -222,6 +224,13 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             half_t* Crow = Cb + (size_t)i * 16 * g.ldc;
+            if (g.phase) {
+                // GEMM row m = (b, y, x) of the LOW-resolution grid; this launch slice (z = py*2 + px) owns the
+                // output pixels (2y + py, 2x + px) of the 2x-upsampled map
+                const int m = row0 + i * 16;
+                const int hw = g.Ho * g.Wo, b = m / hw, rem = m - b * hw, y = rem / g.Wo, x = rem - y * g.Wo;
+                Crow = Cb + ((size_t)(b * 2 * g.Ho + 2 * y + (z >> 1)) * (2 * g.Wo) + 2 * x + (z & 1)) * g.ldc;
+            }
             half4 rr[RES ? NI : 1];
             if constexpr (RES) {
                 const half_t* Rrow = Rb + (size_t)i * 16 * g.ldr;
@@ -868,8 +877,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
             const int b = mm / hw, rem = mm - b * hw;
             const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
             a_off[i] = b * g.Hi * g.Wi * g.Cin + ck * 8;
-            a_yx[i] = ok ? ((unsigned)(oy * g.stride - g.pad_t + 16) << 16) |
-                               (unsigned)(ox * g.stride - g.pad_l + 16)
+            // phase mode: the 2x2 window of output parity (py, px) = (z >> 1, z & 1) starts one row / column earlier for parity 0
+            const int pad_t = g.phase ? 1 - (z >> 1) : g.pad_t, pad_l = g.phase ? 1 - (z & 1) : g.pad_l;
+            a_yx[i] = ok ? ((unsigned)(oy * g.stride - pad_t + 16) << 16) |
+                               (unsigned)(ox * g.stride - pad_l + 16)
                          : 0xffff0000u;
             a_voff[i] = a_bytes;
         } else {
@@ -1419,7 +1430,7 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         const int occ = (BM >= 256 || lds > 80 * 1024) ? 1 : (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);  // workgroups / CU
         const int slots = 256 * occ;
         const int nkt = (g.K + BK - 1) / BK / g.split_k;
-        const bool persistent = NS == 2 && BN != 320 && g.K2 == 0 && (g_persist_mode == 2 ||
+        const bool persistent = NS == 2 && BN != 320 && g.K2 == 0 && !g.phase && (g_persist_mode == 2 ||
                                 (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots));
         if constexpr (EPI >= 1 && EPI <= 3) {
             // the persistent loop does not stage the per-sample bias: generic epilogue there
@@ -1568,12 +1579,24 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         g.mode = MODE_CONV;
         g.Hi = d->in_h; g.Wi = d->in_w; g.Cin = d->in_c; g.Ho = d->out_h; g.Wo = d->out_w;
         g.KW = d->kw; g.stride = d->stride; g.pad_t = d->pad_t; g.pad_l = d->pad_l;
-        g.up = d->upsample2x;
+        g.up = d->upsample2x == 1;
+        g.phase = d->upsample2x == 2;
         FD_CHECK_ARG(d->in_c % BK == 0, FD_ESHAPE,
                      "fd_gemm_f16: conv needs Cin %% 64 == 0 (got %d); use fd_im2col_f16", d->in_c);
         FD_CHECK_ARG(d->K == d->kh * d->kw * d->in_c, FD_EINVAL, "fd_gemm_f16: K != kh*kw*Cin");
         FD_CHECK_ARG(d->M % (d->out_h * d->out_w) == 0, FD_EINVAL,
                      "fd_gemm_f16: M is not a multiple of out_h*out_w");
+        if (g.phase) {
+            // nearest-2x upsample + 3x3 conv as four 2x2 convolutions of the LOW-resolution input, one per output-pixel
+            // parity (batch = 4 = blockIdx.z, weights pre-summed per parity): 4/9 of the MACs.  Only through the lean
+            // plain epilogue (it maps GEMM rows to the interleaved output pixels).
+            FD_CHECK_ARG(batch == 4 && d->kh == 2 && d->kw == 2 && d->stride == 1 && d->out_h == d->in_h && d->out_w == d->in_w &&
+                             d->batch_stride_a == 0 && d->batch_stride_c == 0 && !d->out_f32 && !d->residual && !d->bias2 &&
+                             d->act == FD_ACT_NONE && !d->trans_out && d->ldc % 8 == 0 &&
+                             g_fast_epi && g_bias_lds && g_use_dma,
+                         FD_ESHAPE, "fd_gemm_f16: upsample2x == 2 needs batch 4, a 2x2 kernel, stride 1, out = in size, plain fp16 "
+                                    "output and the lean epilogue on the LDS-DMA path");
+        }
     } else {
         FD_CHECK_ARG(d->lda % 8 == 0, FD_ESHAPE, "fd_gemm_f16: lda=%d must be a multiple of 8",
                      d->lda);
@@ -1742,6 +1765,22 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
             best_tile = geglu ? 1 : (g.N % 160 == 0 ? 2 : 1);   // 128x160 / 128x128, 4 waves
             if (g.N <= 64) best_tile = 3;
         }
+    }
+    if (g.phase) {
+        // only the lean plain epilogue knows the parity row map: the chosen tile must have one and every tile must be full
+        int bm = 0, bn = 0;
+        switch (best_tile) {
+            case 9: case 12: case 20: bm = 128; bn = 160; break;
+            case 10: bm = 128; bn = 128; break;
+            case 13: bm = 256; bn = 160; break;
+            case 14: bm = 256; bn = 128; break;
+            case 15: bm = 256; bn = 256; break;
+            case 16: bm = 256; bn = 320; break;
+            default: break;
+        }
+        FD_CHECK_ARG(bm && g.M % bm == 0 && g.N % bn == 0 && best_split == 1, FD_ESHAPE,
+                     "fd_gemm_f16: upsample2x == 2: tile %d / split %d cannot run M=%d N=%d through the lean epilogue",
+                     best_tile, best_split, g.M, g.N);
     }
     if (best_split > 1)
         FD_CHECK_ARG(!geglu && batch == 1 && g.N % 4 == 0 && g.ws &&

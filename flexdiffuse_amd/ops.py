@@ -172,6 +172,58 @@ def prep_conv_shortcut(w: torch.Tensor, b: Optional[torch.Tensor], ws: torch.Ten
     return ConvW(wd, _bias(bias if torch.is_tensor(bias) else None, dev), cout, cin, kh, kw, False, k, cx)
 
 
+def prep_conv_up_phases(w: torch.Tensor, b: Optional[torch.Tensor], dev) -> ConvW:
+    '''3x3 weights of an Upsample2D conv [Cout][Cin][3][3] -> the four 2x2 parity filters of the phase-decomposed form
+    (fd_gemm_desc.upsample2x == 2): out[2y+py][2x+px] = sum over a 2x2 window of the LOW-resolution input, with the
+    3x3 taps that land on the same source pixel summed (fp32, rounded to fp16 once): rows {0 | 1+2} for py = 0,
+    {0+1 | 2} for py = 1, same for columns.  Layout [4][Cout][2*2*Cin], K contiguous.'''
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and cin % 64 == 0
+    w32 = w.float()
+    rows = {0: (w32[:, :, 0:1].sum(2), w32[:, :, 1:3].sum(2)), 1: (w32[:, :, 0:2].sum(2), w32[:, :, 2:3].sum(2))}   # [Cout][Cin][3]
+    out = torch.zeros((4, cout, 2, 2, cin), dtype=torch.float32)
+    for py in (0, 1):
+        for a in (0, 1):
+            r = rows[py][a]                                   # [Cout][Cin][kw]
+            cols = {0: (r[:, :, 0:1].sum(2), r[:, :, 1:3].sum(2)), 1: (r[:, :, 0:2].sum(2), r[:, :, 2:3].sum(2))}
+            for px in (0, 1):
+                for bb in (0, 1):
+                    out[py * 2 + px, :, a, bb, :] = cols[px][bb]
+    wd = out.reshape(4, cout, 4 * cin).to(dev, torch.float16).contiguous()
+    cw = ConvW(wd, _bias(b, dev), cout, cin, 2, 2, False, 4 * cin)
+    return cw
+
+
+def conv2d_up_phases(x: Act, w: ConvW, out: Optional[torch.Tensor] = None) -> Act:
+    '''nearest-2x upsample + conv3x3 (diffusers Upsample2D) as four 2x2 parity convolutions of the low-resolution
+    input in ONE launch (4/9 of the MACs of the fused-upsample form conv2d(..., up=True)); `w` from prep_conv_up_phases.'''
+    assert x.C == w.cin and w.w.dim() == 3 and w.w.shape[0] == 4 and x.t.is_contiguous()
+    M = x.B * x.H * x.W
+    Ho, Wo = 2 * x.H, 2 * x.W
+    if out is None:
+        out = _empty((x.B * Ho * Wo, w.cout), torch.float16, x.t)
+    assert out.shape == (x.B * Ho * Wo, w.cout) and out.stride(1) == 1
+    d = fd_gemm_desc()
+    d.A, d.W, d.C = x.t.data_ptr(), w.w.data_ptr(), out.data_ptr()
+    d.bias = _p(w.bias)
+    d.M, d.N, d.K = M, w.cout, w.kpad
+    d.ldw, d.ldc = w.w.stride(1), out.stride(0)
+    d.rows_per_sample, d.alpha = x.H * x.W, 1.0
+    d.conv, d.in_h, d.in_w, d.in_c, d.out_h, d.out_w, d.kh, d.kw = 1, x.H, x.W, w.cin, x.H, x.W, 2, 2
+    d.stride, d.pad_t, d.pad_l, d.upsample2x = 1, 1, 1, 2
+    d.batch, d.batch_stride_w = 4, w.w.stride(0)
+    _sched(d, x.t.device)
+    hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+    return Act(out, x.B, Ho, Wo)
+
+
+def up_phases_supported(rows_low: int, cout: int, cin: int) -> bool:
+    '''Shapes for which conv2d_up_phases is used instead of conv2d(..., up=True): full 256-row tiles, UNet / VAE widths,
+    and enough low-resolution rows that four parity slices fill the chip without split-K.'''
+    return (os.environ.get('FD_UP_PHASES', '1') != '0' and rows_low % 256 == 0 and rows_low >= 4096
+            and (cout % 160 == 0 or cout % 128 == 0) and cin % 64 == 0)
+
+
 def f32(t: torch.Tensor, dev) -> torch.Tensor:
     return t.to(dev, torch.float32).contiguous()
 

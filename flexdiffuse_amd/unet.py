@@ -167,6 +167,11 @@ class UNet2DConditionModel():
             if has_up:
                 blk['up'] = ops.prep_conv(sd[f'up_blocks.{i}.upsamplers.0.conv.weight'],
                                           sd[f'up_blocks.{i}.upsamplers.0.conv.bias'], dev)
+                # the same layer as four 2x2 parity convolutions of the low-resolution input (4/9 of the MACs): used
+                # where the low-resolution map has enough rows to fill the chip (ops.up_phases_supported)
+                blk['up_ph'] = ops.prep_conv_up_phases(sd[f'up_blocks.{i}.upsamplers.0.conv.weight'],
+                                                       sd[f'up_blocks.{i}.upsamplers.0.conv.bias'], dev) \
+                    if blk['up'].cin % 64 == 0 and not blk['up'].im2col else None
             self.up.append(blk)
         self.out_g, self.out_b = ops.f32(sd['conv_norm_out.weight'], dev), ops.f32(sd['conv_norm_out.bias'], dev)
         self.conv_out = ops.prep_conv(sd['conv_out.weight'], sd['conv_out.bias'], dev)
@@ -434,8 +439,11 @@ class UNet2DConditionModel():
                 else:
                     h = self._res(r, h, temb, out=dst)
             if blk['up'] is not None:
-                h = ops.conv2d(h, blk['up'], up=True,
-                               out=left(h.B * h.HW * 4, blk['up'].cout))
+                dst = left(h.B * h.HW * 4, blk['up'].cout)
+                if blk.get('up_ph') is not None and ops.up_phases_supported(h.B * h.HW, blk['up'].cout, blk['up'].cin):
+                    h = ops.conv2d_up_phases(h, blk['up_ph'], out=dst)
+                else:
+                    h = ops.conv2d(h, blk['up'], up=True, out=dst)
         h = ops.groupnorm(h, self.out_g, self.out_b, self.G, 1e-5, True)
         return ops.conv2d(h, self.conv_out, out_f32=True).t
 

@@ -90,6 +90,12 @@ class AutoencoderKL():
             res = [_VRes(sd, f'decoder.up_blocks.{i}.resnets.{j}', dev)
                    for j in range(cfg.layers_per_block + 1)]
             up = conv(f'decoder.up_blocks.{i}.upsamplers.0.conv') if i != len(rev) - 1 else None
+            if up is not None and up.cin % 64 == 0 and not up.im2col:
+                # Upsample2D as four 2x2 parity convolutions of the low-resolution map (4/9 of the MACs)
+                n = f'decoder.up_blocks.{i}.upsamplers.0.conv'
+                up = (up, ops.prep_conv_up_phases(sd[n + '.weight'], sd[n + '.bias'], dev))
+            elif up is not None:
+                up = (up, None)
             self.d_up.append((res, up))
         self.d_out_g, self.d_out_b = ops.f32(sd['decoder.conv_norm_out.weight'], dev), \
             ops.f32(sd['decoder.conv_norm_out.bias'], dev)
@@ -159,7 +165,10 @@ class AutoencoderKL():
             for r in res:
                 h = self._res(r, h)
             if up is not None:
-                h = ops.conv2d(h, up, up=True)
+                if up[1] is not None and ops.up_phases_supported(h.B * h.HW, up[0].cout, up[0].cin) and h.t.is_contiguous():
+                    h = ops.conv2d_up_phases(h, up[1])
+                else:
+                    h = ops.conv2d(h, up[0], up=True)
         h = ops.groupnorm(h, self.d_out_g, self.d_out_b, self.G, 1e-6, True)
         return ops.conv2d(h, self.d_conv_out, out_f32=True)
 

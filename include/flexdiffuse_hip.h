@@ -155,7 +155,14 @@ typedef struct fd_gemm_desc {
     int32_t act;             /* FD_ACT_* */
     int32_t out_f32;
     float alpha;             /* scales the accumulator before bias; 0 means 1 */
-    /* implicit-GEMM convolution (conv != 0): in_c % 64 == 0, K = kh*kw*in_c */
+    /* implicit-GEMM convolution (conv != 0): in_c % 64 == 0, K = kh*kw*in_c.
+     * upsample2x: 1 = the input is read through a fused nearest-2x upsample (in_h / in_w are the LOW-resolution size).
+     * 2 = PHASE-DECOMPOSED upsample convolution: diffusers' Upsample2D (nearest 2x, then conv3x3; inside `unet(...)`,
+     * reference pipeline/guide.py:56-58, and `vae.decode`, pipeline/flex.py:118) computed as four 2x2 convolutions of the
+     * low-resolution input, one per output-pixel parity (py, px) = (z >> 1, z & 1) with batch = 4: W is [4][N][2*2*in_c]
+     * (batch_stride_w = N * ldw), the 3x3 taps that fall on the same source pixel pre-summed per parity (4/9 of the MACs,
+     * same sums); M = B * in_h * in_w rows of the low-resolution grid, out_h = in_h, out_w = in_w, kh = kw = 2, and C is the
+     * FULL-resolution [B][2 in_h][2 in_w][ldc] map into which slice z writes the pixels (2y + py, 2x + px). */
     int32_t conv, in_h, in_w, in_c, out_h, out_w, kh, kw, stride, pad_t, pad_l, upsample2x;
     /* transposed store: C is [sample][N][trans_ld] (row n, column m within the sample) */
     int32_t trans_out, trans_ld;

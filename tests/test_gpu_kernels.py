@@ -556,3 +556,33 @@ def test_gemm_with_appended_operand_folds_two_linears(dev, M, C):
     assert float((got - want).abs().mean()) <= float((two - want).abs().mean()) * 1.1 + 1e-5
     with pytest.raises(AssertionError):
         ops.gemm(fd, lw, residual=xd)      # K mismatch without the second operand
+
+
+@pytest.mark.parametrize('B,H,Cin,Cout', [(16, 32, 640, 640), (16, 16, 1280, 1280), (2, 64, 512, 512), (1, 128, 256, 256),
+                                          (4, 32, 128, 128)])
+def test_upsample_conv_phase_decomposition(dev, B, H, Cin, Cout):
+    '''fd_gemm_desc.upsample2x == 2: nearest-2x upsample + conv3x3 (diffusers Upsample2D) as four 2x2 parity convolutions
+    of the low-resolution input in one launch (4/9 of the MACs) vs (a) torch fp32 F.interpolate + conv2d and (b) the
+    fused-upsample implicit GEMM it replaces.  The parity filters are the 3x3 taps summed in fp32 and rounded once, so
+    (b) differs by weight rounding only.  Shapes: the UNet's two large upsamplers, VAE-like widths, into a strided
+    output (the decoder's concat buffer).'''
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(B + H + Cin)
+    x = (torch.randn((B, Cin, H, H), generator=g) * 0.7).half()
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) * (9 * Cin) ** -0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    want = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode='nearest'), w.float(), b, padding=1)
+    want = want.permute(0, 2, 3, 1).reshape(B * 4 * H * H, Cout)
+    xd = ops.Act(x.permute(0, 2, 3, 1).reshape(B * H * H, Cin).contiguous().to(dev), B, H, H)
+    assert ops.up_phases_supported(B * H * H, Cout, Cin)
+    buf = torch.zeros((B * 4 * H * H, Cout + 64), dtype=torch.float16, device=dev)     # strided destination
+    got = ops.conv2d_up_phases(xd, ops.prep_conv_up_phases(w, b, dev), out=buf[:, :Cout])
+    assert (got.B, got.H, got.W) == (B, 2 * H, 2 * H)
+    gotf = got.t.float().cpu()
+    old = ops.conv2d(xd, ops.prep_conv(w, b, dev), up=True).t.float().cpu()
+    tol = 4e-3 * float(want.abs().max()) + 2e-3
+    assert float((gotf - want).abs().max()) <= tol, float((gotf - want).abs().max())
+    assert float((gotf - old).abs().max()) <= tol
+    assert float((gotf - want).abs().mean()) <= 1.2 * float((old - want).abs().mean()) + 1e-5
+    assert float(buf[:, Cout:].abs().max()) == 0.0           # nothing written past the view
+    assert not ops.up_phases_supported(1024, Cout, Cin)      # too few rows: stays on the fused-upsample conv
