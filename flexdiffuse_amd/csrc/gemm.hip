@@ -1637,7 +1637,9 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         g.ldb2 = 0;
     }
     hipStream_t st = (hipStream_t)stream;
-    const double flops = 2.0 * (double)d->M * d->N * ((double)d->K + d->K2) * batch;
+    // priced at the ALGORITHMIC work of the op it implements: the phase-decomposed upsample convolution (batch 4, K = 4 Cin)
+    // stands for a 3x3 convolution over the 4 M upsampled pixels (K = 9 Cin), of which it executes 4/9 of the MACs
+    const double flops = (d->conv && d->upsample2x == 2 ? 2.25 : 1.0) * 2.0 * (double)d->M * d->N * ((double)d->K + d->K2) * batch;
     g.split_k = 1;
     g.bias_lds = g_bias_lds;
     g.ws = (float*)d->workspace;

@@ -220,7 +220,8 @@ def conv2d_up_phases(x: Act, w: ConvW, out: Optional[torch.Tensor] = None) -> Ac
 def up_phases_supported(rows_low: int, cout: int, cin: int) -> bool:
     '''Shapes for which conv2d_up_phases is used instead of conv2d(..., up=True): full 256-row tiles, UNet / VAE widths,
     and enough low-resolution rows that four parity slices fill the chip without split-K.'''
-    return (os.environ.get('FD_UP_PHASES', '1') != '0' and rows_low % 256 == 0 and rows_low >= 4096
+    return (os.environ.get('FD_UP_PHASES', '1') != '0' and rows_low % 256 == 0
+            and rows_low >= int(os.environ.get('FD_UP_PHASES_MIN_ROWS', '4096'))
             and (cout % 160 == 0 or cout % 128 == 0) and cin % 64 == 0)
 
 
