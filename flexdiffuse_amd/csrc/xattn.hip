@@ -33,58 +33,83 @@ typedef const __attribute__((address_space(3))) floatx4* xlds_cf4;
 
 struct XattnArgs {
     const half_t* A;        // hidden states [M][lda], un-normalised
-    const half_t* W;        // [320][ldw] gain-folded, pre-scaled q weights
-    const float* bias;      // [320] folded bias
-    const float* colsum;    // [320] column sums of the folded weights
+    const half_t* W;        // [C][ldw] gain-folded, pre-scaled q weights
+    const float* bias;      // [C] folded bias
+    const float* colsum;    // [C] column sums of the folded weights
     const float* ln_stats;  // [M][2] (rstd, -mean rstd)
-    const char* kimg;       // [samples][XA_KIMG] K images
-    const char* vimg;       // [samples][XA_VIMG] V^T images
+    const char* kimg;       // [samples][n-tiles][image] K images
+    const char* vimg;       // [samples][n-tiles][image] V^T images
     half_t* O;              // [nrep * M][ldo]
     int M, lda, ldw, ldo;
-    int rows_per_sample, nrep, samples_per_rep, n_keys;
+    int rows_per_sample, samples_per_rep, n_keys;
 };
 
-constexpr int XA_HEADS = 8, XA_D = 40, XA_C = 320;
-constexpr int XA_KB = 5;                                   // 16-key blocks (80 >= 77 keys)
-constexpr int XA_KHEAD = XA_KB * 1536;                     // per head: 5 x (1024 B k32 + 512 B k16)
-constexpr int XA_KIMG = XA_HEADS * XA_KHEAD;               // 61,440 B
-constexpr int XA_VHEAD = 3 * 2560;                         // per head: 3 d-tiles x (1024 + 1024 + 512 B)
-constexpr int XA_VIMG = XA_HEADS * XA_VHEAD;               // 61,440 B
+constexpr int XA_KB = 5;   // 16-key blocks (80 >= 77 keys)
+
+// Shape classes.  D = 40 (C = 320: the 64x64 level of SD1.x): 256-row tiles, a wave owns a head PAIR (80 columns);
+// D = 80 (C = 640: the 32x32 level): 128-row tiles, two 320-column n-tiles of four heads, a wave owns ONE head.
+template <int D> struct XaCfg;
+template <> struct XaCfg<40> {
+    static constexpr int BM = 256, HPW = 2, HEADS_TILE = 8, KSF = 1, DT = 3, C = 320;
+    static constexpr bool ONES = true;
+};
+template <> struct XaCfg<80> {
+    static constexpr int BM = 128, HPW = 1, HEADS_TILE = 4, KSF = 2, DT = 5, C = 640;
+    static constexpr bool ONES = false;
+};
+template <int D> constexpr int xa_khead() { return XA_KB * (XaCfg<D>::KSF * 1024 + 512); }   // K image bytes per head
+template <int D> constexpr int xa_vhead() { return XaCfg<D>::DT * 2560; }                    // V^T image bytes per head
+template <int D> constexpr int xa_kimg() { return XaCfg<D>::HEADS_TILE * xa_khead<D>(); }    // per (sample, n-tile)
+template <int D> constexpr int xa_vimg() { return XaCfg<D>::HEADS_TILE * xa_vhead<D>(); }
 
 // ---- image packing (once per context) ---------------------------------------------------------
-// K image, head h, key block kb: [k32: lane (fr, fq) -> 8 halfs][k16: lane -> 4 halfs], key = kb*16 + fr.
-//   even head (A of its pair): k32 = {ch fq*4 + 0..3, ch 16 + fq*4 + 0..3}; k16 = ch 32 + fq*4 + 0..3 for fq < 2, else 0
-//   odd head  (B of its pair): k32 = {ch 8 + fq*4 + 0..3, ch 24 + fq*4 + 0..3}; k16 = ch (fq-2)*4 + 0..3 for fq >= 2, else 0
-// V^T image, head h, d-tile dt (row d = dt*16 + fr; d == 40: ones, 41..47: zero), key group kg:
-//   kg 0 / 1 (k32): {key (2kg)*16 + fq*4 + 0..3, key (2kg+1)*16 + fq*4 + 0..3};  kg 2 (k16): key 64 + fq*4 + 0..3
-// Keys >= n_keys are zero everywhere (ones-row included), so padded keys add nothing.
+// K image, head h, key block kb (key = kb*16 + fr, lane = (fr, fq)): KSF fragments of 8 halfs per lane, then a 4-half tail.
+//   D = 40, even head (A of its pair): k32 = {ch fq*4 + 0..3, ch 16 + fq*4 + 0..3}; tail = ch 32 + fq*4 + 0..3 for fq < 2, else 0
+//   D = 40, odd head  (B of its pair): k32 = {ch 8 + fq*4 + 0..3, ch 24 + fq*4 + 0..3}; tail = ch (fq-2)*4 + 0..3 for fq >= 2, else 0
+//     (the wave's fragment 2 holds A's channels 32..39 and B's channels 0..7: each head's image is zero at the other's k-slots)
+//   D = 80: k32[ks] = {ch ks*32 + fq*4 + 0..3, ch ks*32 + 16 + fq*4 + 0..3}, tail = ch 64 + fq*4 + 0..3
+// V^T image, head h, d-tile dt (row d = dt*16 + fr), key group kg: kg 0 / 1 (8 halfs): {key (2kg)*16 + fq*4 + 0..3,
+//   key (2kg+1)*16 + fq*4 + 0..3}; kg 2 (4 halfs): key 64 + fq*4 + 0..3.  D = 40: row 40 = ones (the softmax denominator
+//   rides through the PV MFMA), rows 41..47 zero.  Keys >= n_keys are zero everywhere (ones-row included).
+template <int D>
 __global__ void k_xattn_pack(const half_t* __restrict__ K, const half_t* __restrict__ Vt, char* __restrict__ kimg,
-                             char* __restrict__ vimg, int L, int ldk, int ldvt, long long sK, long long sVt) {
+                             char* __restrict__ vimg, int L, int ldk, int ldvt, long long sK, long long sVt, int heads) {
+    typedef XaCfg<D> cfg;
     const int b = blockIdx.y, h = blockIdx.x;
-    const half_t* Kb = K + (size_t)b * sK + h * XA_D;
-    const half_t* Vb = Vt + (size_t)b * sVt + (size_t)h * XA_D * ldvt;
-    half_t* ki = reinterpret_cast<half_t*>(kimg + (size_t)b * XA_KIMG + (size_t)h * XA_KHEAD);
-    half_t* vi = reinterpret_cast<half_t*>(vimg + (size_t)b * XA_VIMG + (size_t)h * XA_VHEAD);
+    const half_t* Kb = K + (size_t)b * sK + h * D;
+    const half_t* Vb = Vt + (size_t)b * sVt + (size_t)h * D * ldvt;
+    // images of a sample: [n-tile][head within tile]; heads are consecutive, so head h sits at h * per-head bytes
+    half_t* ki = reinterpret_cast<half_t*>(kimg + ((size_t)b * heads + h) * xa_khead<D>());
+    half_t* vi = reinterpret_cast<half_t*>(vimg + ((size_t)b * heads + h) * xa_vhead<D>());
+    constexpr int KBH = (cfg::KSF * 1024 + 512) / 2;    // halfs per key block
     const bool odd = h & 1;
     for (int e = threadIdx.x; e < XA_KB * 64; e += blockDim.x) {
         const int kb = e >> 6, lane = e & 63, fr = lane & 15, fq = lane >> 4;
         const int key = kb * 16 + fr;
-        half_t* o32 = ki + kb * 768 + lane * 8;          // 1536 B = 768 halfs per key block
-        half_t* o16 = ki + kb * 768 + 512 + lane * 4;
-        for (int i = 0; i < 8; ++i) {
-            const int ch = (odd ? 8 : 0) + (i < 4 ? fq * 4 + i : 16 + fq * 4 + (i - 4));
-            o32[i] = key < L ? Kb[(size_t)key * ldk + ch] : (half_t)0.f;
+        for (int ks = 0; ks < cfg::KSF; ++ks) {
+            half_t* o32 = ki + kb * KBH + ks * 512 + lane * 8;
+            for (int i = 0; i < 8; ++i) {
+                int ch;
+                if (D == 40) ch = (odd ? 8 : 0) + (i < 4 ? fq * 4 + i : 16 + fq * 4 + (i - 4));
+                else ch = ks * 32 + (i < 4 ? fq * 4 + i : 16 + fq * 4 + (i - 4));
+                o32[i] = key < L ? Kb[(size_t)key * ldk + ch] : (half_t)0.f;
+            }
         }
+        half_t* o16 = ki + kb * KBH + cfg::KSF * 512 + lane * 4;
         for (int i = 0; i < 4; ++i) {
             half_t v = (half_t)0.f;
             if (key < L) {
-                if (!odd && fq < 2) v = Kb[(size_t)key * ldk + 32 + fq * 4 + i];
-                if (odd && fq >= 2) v = Kb[(size_t)key * ldk + (fq - 2) * 4 + i];
+                if (D == 40) {
+                    if (!odd && fq < 2) v = Kb[(size_t)key * ldk + 32 + fq * 4 + i];
+                    if (odd && fq >= 2) v = Kb[(size_t)key * ldk + (fq - 2) * 4 + i];
+                } else {
+                    v = Kb[(size_t)key * ldk + 64 + fq * 4 + i];
+                }
             }
             o16[i] = v;
         }
     }
-    for (int e = threadIdx.x; e < 3 * 3 * 64; e += blockDim.x) {
+    for (int e = threadIdx.x; e < cfg::DT * 3 * 64; e += blockDim.x) {
         const int lane = e & 63, kg = (e >> 6) % 3, dt = e / 192, fr = lane & 15, fq = lane >> 4;
         const int d = dt * 16 + fr;
         half_t* o = vi + dt * 1280 + (kg == 0 ? 0 : kg == 1 ? 512 : 1024) + lane * (kg == 2 ? 4 : 8);
@@ -94,12 +119,19 @@ __global__ void k_xattn_pack(const half_t* __restrict__ K, const half_t* __restr
                                     : (i < 4 ? (2 * kg) * 16 + fq * 4 + i : (2 * kg + 1) * 16 + fq * 4 + (i - 4));
             half_t v = (half_t)0.f;
             if (key < L) {
-                if (d < XA_D) v = Vb[(size_t)d * ldvt + key];
-                else if (d == XA_D) v = (half_t)1.f;
+                if (d < D) v = Vb[(size_t)d * ldvt + key];
+                else if (cfg::ONES && d == D) v = (half_t)1.f;
             }
             o[i] = v;
         }
     }
+}
+
+static bool xa_supported(int heads, int head_dim) { return heads == 8 && (head_dim == 40 || head_dim == 80); }
+
+extern "C" int64_t fd_xattn_image_bytes(int heads, int head_dim) {
+    if (!xa_supported(heads, head_dim)) return 0;
+    return head_dim == 40 ? (int64_t)heads * xa_khead<40>() : (int64_t)heads * xa_khead<80>();   // K and V^T images: same size
 }
 
 extern "C" int fd_xattn_pack_kv_f16(const void* K, const void* Vt, void* kimg, void* vimg, int samples, int n_keys,
@@ -108,72 +140,60 @@ extern "C" int fd_xattn_pack_kv_f16(const void* K, const void* Vt, void* kimg, v
     FD_PLAN(fd_xattn_pack_kv_f16(K, Vt, kimg, vimg, samples, n_keys, heads, head_dim, ldk, ldvt, k_sample_stride,
                                  vt_sample_stride, fd_s_));
     FD_CHECK_ARG(K && Vt && kimg && vimg && samples > 0, FD_EINVAL, "fd_xattn_pack_kv_f16: args");
-    FD_CHECK_ARG(heads == XA_HEADS && head_dim == XA_D && n_keys >= 1 && n_keys <= 80, FD_ESHAPE,
-                 "fd_xattn_pack_kv_f16: 8 heads x 40, at most 80 keys (got %d x %d, %d keys)", heads, head_dim, n_keys);
+    FD_CHECK_ARG(xa_supported(heads, head_dim) && n_keys >= 1 && n_keys <= 80, FD_ESHAPE,
+                 "fd_xattn_pack_kv_f16: 8 heads x 40 or 8 x 80, at most 80 keys (got %d x %d, %d keys)", heads, head_dim, n_keys);
     FD_CHECK_ARG(ldvt >= n_keys && ldk >= heads * head_dim, FD_ESHAPE, "fd_xattn_pack_kv_f16: leading dimensions");
-    hipLaunchKernelGGL(k_xattn_pack, dim3(XA_HEADS, samples), dim3(256), 0, (hipStream_t)stream, (const half_t*)K,
-                       (const half_t*)Vt, (char*)kimg, (char*)vimg, n_keys, ldk, ldvt, (long long)k_sample_stride,
-                       (long long)vt_sample_stride);
+    static_assert(xa_khead<40>() == xa_vhead<40>() && xa_khead<80>() == xa_vhead<80>(), "K and V^T images share a size");
+    if (head_dim == 40)
+        hipLaunchKernelGGL(k_xattn_pack<40>, dim3(heads, samples), dim3(256), 0, (hipStream_t)stream, (const half_t*)K,
+                           (const half_t*)Vt, (char*)kimg, (char*)vimg, n_keys, ldk, ldvt, (long long)k_sample_stride,
+                           (long long)vt_sample_stride, heads);
+    else
+        hipLaunchKernelGGL(k_xattn_pack<80>, dim3(heads, samples), dim3(256), 0, (hipStream_t)stream, (const half_t*)K,
+                           (const half_t*)Vt, (char*)kimg, (char*)vimg, n_keys, ldk, ldvt, (long long)k_sample_stride,
+                           (long long)vt_sample_stride, heads);
     FD_CHECK_LAUNCH("k_xattn_pack");
     return FD_OK;
 }
 
-extern "C" int64_t fd_xattn_image_bytes(int heads, int head_dim) {
-    return (heads == XA_HEADS && head_dim == XA_D) ? (int64_t)XA_KIMG : 0;   // K and V^T images have the same size
-}
-
-// The 16-wide remainder of a contraction (8 channels of head dim 40; keys 64..79).  The image keeps
-// it as 4 halfs per lane (half the LDS bytes of a K = 32 fragment); the MFMA is the K = 32 form on
-// zero-extended operands: v_mfma_f32_16x16x16_f16 occupies the matrix pipe just as long
-// (profiles/r02_micro_mfma_k16.txt), and a dependent chain that MIXES the two forms on one
-// accumulator gave run-to-run different sums here (FD_XATTN_K16=1 builds that form for the record).
-#ifndef FD_XATTN_K16
-#define FD_XATTN_K16 0
-#endif
-__device__ __forceinline__ floatx4 xa_mfma_tail(half4 a, half4 b, floatx4 c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#if FD_XATTN_K16
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
-#else
-    const half_t z = (half_t)0.f;
-    const half8 a8 = {a[0], a[1], a[2], a[3], z, z, z, z}, b8 = {b[0], b[1], b[2], b[3], z, z, z, z};
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, c, 0, 0, 0);
-#endif
-#else
-    return c;
-#endif
-}
-#define XA_MFMA_TAIL(A4, B4, C) xa_mfma_tail((A4), (B4), (C))
-
 // ---- the fused kernel -------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes, unsigned w_bytes, unsigned o_bytes) {
+// grid: (row tiles, context replicas, 320-column n-tiles).  Replicas sharing the queries (CFG fan-out of a shared prefix)
+// are a grid dimension: the q tile is recomputed per replica -- at those shapes half the CUs would otherwise idle.
+template <int D>
+__global__ __launch_bounds__(1024) void k_xattn(XattnArgs g, unsigned a_bytes, unsigned w_bytes, unsigned o_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BM = 256, BN = 320, WM = 4, WN = 4, NW = 16;
-    constexpr int WTM = 64, WTN = 80, MI = 4, NI = 5;
-    constexpr int AG = BM / 8, BG = BN / 8;            // 8-row DMA groups: 32 / 40
-    constexpr int AR = AG / NW, BR = (BG + NW - 1) / NW;   // 2 / 3 DMA instructions per wave
-    constexpr int STAGE = (BM + BN) * 128;             // 73,728 B >= one image
-    static_assert(STAGE >= XA_KIMG && STAGE >= XA_VIMG, "an image must fit one dead K-loop stage");
+    typedef XaCfg<D> cfg;
+    constexpr int BM = cfg::BM, BN = 320, WN = 4, NW = 16;
+    constexpr int WTM = BM / 4, WTN = 80, MI = WTM / 16, NI = 5;
+    constexpr int AG = BM / 8, BG = BN / 8;            // 8-row DMA groups
+    constexpr int AR = AG / NW, BR = (BG + NW - 1) / NW;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int KIMG = xa_kimg<D>(), VIMG = xa_vimg<D>(), KHEAD = xa_khead<D>(), VHEAD = xa_vhead<D>();
+    constexpr int KBB = cfg::KSF * 1024 + 512;          // K image bytes per key block
+    static_assert(STAGE >= KIMG && STAGE >= VIMG, "an image must fit one dead K-loop stage");
+    static_assert(AG % NW == 0 && MI % 2 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware tile order (workgroups round-robin over the 8 XCDs): each XCD takes a contiguous range of row
-    // tiles, i.e. whole samples, so a sample's 120 KB of K / V^T images is fetched into ONE XCD's L2 instead of
-    // all eight (PMC, round-robin order: 60.1 MB read per launch for 42 MB of hidden states + 2 MB of images)
+    // XCD-aware tile order (workgroups round-robin over the 8 XCDs; grid.x is what varies fastest): each XCD takes a
+    // contiguous range of row tiles, i.e. whole samples, so a sample's K / V^T images are fetched into ONE XCD's L2
+    // instead of all eight (PMC, round-robin order: 60.1 MB read per launch for 42 MB of hidden states + 2 MB of images)
     int tile = blockIdx.x;
     {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = tile & 7, slot = tile >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     const int m0 = tile * BM;
+    const int rep = blockIdx.y, nt = blockIdx.z, ntiles = gridDim.z;
+    const int n0 = nt * BN;
     const int fr = lane & 15, fq = lane >> 4;
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, w_bytes, 0x00020000);
-    float* bias_s = reinterpret_cast<float*>(smem + 2 * STAGE);   // [320] bias | [320] colsum | [256][2] row statistics
+    float* bias_s = reinterpret_cast<float*>(smem + 2 * STAGE);   // [320] bias | [320] colsum | [BM][2] row statistics
     float* stats_s = bias_s + 2 * BN;
     {
         // the tile's LayerNorm row statistics ride along too: a global load in the epilogue would be waited
@@ -183,8 +203,8 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lds_ptr)(stats_s + wave * 64), 4, (unsigned)(wave * 64 + lane) * 4u, 0, 0, 0);
     }
     {
-        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.bias, 0, XA_C * 4u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)g.colsum, 0, XA_C * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(g.bias + n0), 0, BN * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(g.colsum + n0), 0, BN * 4u, 0x00020000);
         if (wave * 64 + lane < BN) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(bias_s + wave * 64), 4, (unsigned)(wave * 64 + lane) * 4u, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsC, (lds_ptr)(bias_s + BN + wave * 64), 4, (unsigned)(wave * 64 + lane) * 4u, 0, 0, 0);
@@ -195,9 +215,9 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
     unsigned a_voff[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) a_voff[i] = (unsigned)((m0 + (i * NW + wave) * 8 + rsub) * g.lda + ck * 8) * 2u;
-    const unsigned b_voff0 = (unsigned)((wave * 8 + rsub) * g.ldw + ck * 8) * 2u;
+    const unsigned b_voff0 = (unsigned)((n0 + wave * 8 + rsub) * g.ldw + ck * 8) * 2u;
     const int b_group = NW * 8 * g.ldw * 2;
-    constexpr int nk = XA_C / XBK;   // 5 K-tiles
+    constexpr int nk = cfg::C / XBK;   // K = C: 5 or 10 K-tiles
 
 #define XA_DMA_TILE(KT, BUF)                                                                     \
     {                                                                                            \
@@ -209,11 +229,11 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
             if (i * NW + wave < BG)                                                              \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(stage + BM * 128 + (i * NW + wave) * 1024), 16, b_voff0, soff + i * b_group, 0, 0); \
     }
-    // an image (61,440 B = 60 x 1 KB, lane-linear) into a dead stage: chunk c by wave c % 16
-#define XA_DMA_IMAGE(RS, BUF)                                                                    \
+    // an image (lane-linear, a multiple of 1 KB) into a dead stage: chunk c by wave c % 16
+#define XA_DMA_IMAGE(RS, BYTES, BUF)                                                             \
     {                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
-            if (i * NW + wave < XA_KIMG / 1024)                                                  \
+        _Pragma("unroll") for (int i = 0; i < ((BYTES) / 1024 + NW - 1) / NW; ++i)               \
+            if (i * NW + wave < (BYTES) / 1024)                                                  \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_ptr)(smem + (BUF) * STAGE + (i * NW + wave) * 1024), 16, \
                                                          (unsigned)lane * 16u, (i * NW + wave) * 1024, 0, 0); \
     }
@@ -224,11 +244,10 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    const int rep = blockIdx.y;
-    // the tile lies in one sample (rows_per_sample % 256 == 0); replica r of sample b is image r * samples + b
-    const size_t sample = (size_t)rep * g.samples_per_rep + m0 / g.rows_per_sample;
-    const __amdgpu_buffer_rsrc_t rsKi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.kimg + sample * XA_KIMG), 0, XA_KIMG, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsVi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.vimg + sample * XA_VIMG), 0, XA_VIMG, 0x00020000);
+    // the tile lies in one sample (rows_per_sample % BM == 0); replica r of sample b is image r * samples + b
+    const size_t img = ((size_t)rep * g.samples_per_rep + m0 / g.rows_per_sample) * ntiles + nt;
+    const __amdgpu_buffer_rsrc_t rsKi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.kimg + img * KIMG), 0, KIMG, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsVi = __builtin_amdgcn_make_buffer_rsrc((void*)(g.vimg + img * VIMG), 0, VIMG, 0x00020000);
 
     XA_DMA_TILE(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -241,7 +260,7 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
         if (kt + 1 < nk) {
             XA_DMA_TILE(kt + 1, cur ^ 1);
         } else {
-            XA_DMA_IMAGE(rsKi, cur ^ 1);   // the other stage is dead during the last K-tile
+            XA_DMA_IMAGE(rsKi, KIMG, cur ^ 1);   // the other stage is dead during the last K-tile
         }
         const char* st = smem + cur * STAGE;
 #pragma unroll
@@ -267,12 +286,13 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
     // here: every wave is past the last K-tile; stage `cur` holds the K image, stage `cur ^ 1` is dead
     const char* sK = smem + cur * STAGE;
     const char* sV = smem + (cur ^ 1) * STAGE;
-    XA_DMA_IMAGE(rsVi, cur ^ 1);
+    XA_DMA_IMAGE(rsVi, VIMG, cur ^ 1);
 
-    // ---- Q = LN-fold(acc) rounded to fp16 (exactly what the unfused q projection stores), held directly as
-    // MFMA B operands: qA = fragments {0,1} (head A, channels 0..31), qB = fragments {3,4} (head B, channels
-    // 8..39), qT = fragment 2 zero-extended (A's channels 32..39 | B's channels 0..7) -------------------------
-    half8 qA[MI], qB[MI], qT[MI];
+    // ---- Q = LN-fold(acc) rounded to fp16 (exactly what the unfused q projection stores), held directly as MFMA B
+    // operands.  D = 40: q0 = fragments {0,1} (head A, channels 0..31), q1 = fragments {3,4} (head B, channels 8..39),
+    // qT = fragment 2 zero-extended (A's channels 32..39 | B's 0..7).  D = 80 (one head per wave): q0 = {0,1},
+    // q1 = {2,3}, qT = fragment 4 zero-extended -------------------------------------------------------------------
+    half8 q0[MI], q1[MI], qT[MI];
     {
         floatx2 st[MI];
 #pragma unroll
@@ -283,110 +303,127 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
         for (int j = 0; j < NI; ++j) {
             const floatx4 bb = *reinterpret_cast<xlds_cf4>((xlds_cfloat)bias_s + wn * WTN + j * 16 + fq * 4);
             const floatx4 cs = *reinterpret_cast<xlds_cf4>((xlds_cfloat)bias_s + BN + wn * WTN + j * 16 + fq * 4);
+            constexpr int JT = D == 40 ? 2 : 4;               // the fragment that becomes the zero-extended tail
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const half_t q = (half_t)fmaf(acc[i][j][r], st[i][0], fmaf(st[i][1], cs[r], bb[r]));
-                    if (j == 0) qA[i][r] = q;
-                    if (j == 1) qA[i][4 + r] = q;
-                    if (j == 2) { qT[i][r] = q; qT[i][4 + r] = (half_t)0.f; }
-                    if (j == 3) qB[i][r] = q;
-                    if (j == 4) qB[i][4 + r] = q;
+                    if (j == JT) { qT[i][r] = q; qT[i][4 + r] = (half_t)0.f; }
+                    else {
+                        const int jj = j < JT ? j : j - 1;    // the four full fragments in order
+                        if (jj == 0) q0[i][r] = q;
+                        if (jj == 1) q0[i][4 + r] = q;
+                        if (jj == 2) q1[i][r] = q;
+                        if (jj == 3) q1[i][4 + r] = q;
+                    }
                 }
             // one fragment column at a time: its accumulators die as its q halves are born (left alone the
-            // scheduler converts everything at once: 80 accumulators + 48 operand registers live -> spills)
+            // scheduler converts everything at once: all accumulators + all operand registers live -> spills)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     const int kb_last_valid = g.n_keys - 64 - fq * 4;   // key 64 + fq*4 + r is real iff r < kb_last_valid
     // output through a buffer descriptor: 32-bit per-lane offsets instead of 64-bit pointers in VGPRs
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)g.O, 0, o_bytes, 0x00020000);
-    const unsigned o_lane = (unsigned)(((m0 + wm * WTM + fr) * g.ldo + wn * WTN + fq * 4) * 2);
-    // context replicas sharing the queries (CFG fan-out of a shared prefix) are a grid dimension: the q tile is
-    // recomputed per replica -- at those shapes (8 samples) half the CUs would otherwise idle
-    bool v_ready = false;
+    const unsigned o_lane = (unsigned)(((m0 + wm * WTM + fr) * g.ldo + n0 + wn * WTN + fq * 4) * 2);
     const unsigned o_rep = (unsigned)rep * (unsigned)g.M * (unsigned)g.ldo * 2u;   // scalar byte offset of the replica
-    {
+    bool v_ready = false;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const char* kh = sK + (wn * 2 + hh) * XA_KHEAD;
-            const char* vh = sV + (wn * 2 + hh) * XA_VHEAD;
+    for (int hh = 0; hh < cfg::HPW; ++hh) {
+        const char* kh = sK + (wn * cfg::HPW + hh) * KHEAD;
+        const char* vh = sV + (wn * cfg::HPW + hh) * VHEAD;
 #pragma unroll
-            for (int ip = 0; ip < 2; ++ip) {
-                // ---- S^T = K Q^T for two 16-query blocks (they share every K fragment read) ----
-                floatx4 s[2][XA_KB];
+        for (int ip = 0; ip < MI / 2; ++ip) {
+            // ---- S^T = K Q^T for two 16-query blocks (they share every K fragment read) ----
+            floatx4 s[2][XA_KB];
 #pragma unroll
-                for (int kb = 0; kb < XA_KB; ++kb) {
-                    const half8 k32 = *reinterpret_cast<const half8*>(kh + kb * 1536 + lane * 16);
-                    const half4 k16 = *reinterpret_cast<const half4*>(kh + kb * 1536 + 1024 + lane * 8);
-                    const half_t z = (half_t)0.f;
-                    const half8 k16x = {k16[0], k16[1], k16[2], k16[3], z, z, z, z};
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int i = ip * 2 + t;
-                        const floatx4 v = __builtin_amdgcn_mfma_f32_16x16x32_f16(k32, hh ? qB[i] : qA[i], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        s[t][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k16x, qT[i], v, 0, 0, 0);
-                    }
-                }
-                // ---- softmax over the n_keys keys (base-2 logits: the scale is folded into Wq); P held as the
-                // B operands of the PV product: pk[t][kg] = key blocks {2 kg, 2 kg + 1}, block 4 zero-extended ----
-                half8 pk[2][3];
+            for (int kb = 0; kb < XA_KB; ++kb) {
+                const half8 ka = *reinterpret_cast<const half8*>(kh + kb * KBB + lane * 16);
+                half8 kbf = ka;
+                if constexpr (D == 80) kbf = *reinterpret_cast<const half8*>(kh + kb * KBB + 1024 + lane * 16);
+                const half4 k16 = *reinterpret_cast<const half4*>(kh + kb * KBB + cfg::KSF * 1024 + lane * 8);
+                const half_t z = (half_t)0.f;
+                const half8 k16x = {k16[0], k16[1], k16[2], k16[3], z, z, z, z};
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r >= kb_last_valid) s[t][4][r] = -INFINITY;
-                    float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
-#pragma unroll
-                    for (int kb = 1; kb < XA_KB; ++kb)
-                        mx = fmaxf(mx, fmaxf(fmaxf(s[t][kb][0], s[t][kb][1]), fmaxf(s[t][kb][2], s[t][kb][3])));
-                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#pragma unroll
-                    for (int kb = 0; kb < XA_KB; ++kb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            pk[t][kb >> 1][(kb & 1) * 4 + r] = (half_t)__builtin_amdgcn_exp2f(s[t][kb][r] - mx);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pk[t][2][4 + r] = (half_t)0.f;
-                }
-                if (!v_ready) {   // first use of the V^T image in this launch
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    v_ready = true;
-                }
-                // ---- O^T = V^T P^T (row 40 of the image is all ones: the softmax denominator) ----
-                floatx4 o[2][3];
-#pragma unroll
-                for (int dt = 0; dt < 3; ++dt) {
-                    const half8 v0 = *reinterpret_cast<const half8*>(vh + dt * 2560 + lane * 16);
-                    const half8 v1 = *reinterpret_cast<const half8*>(vh + dt * 2560 + 1024 + lane * 16);
-                    const half4 v2 = *reinterpret_cast<const half4*>(vh + dt * 2560 + 2048 + lane * 8);
-                    const half_t z = (half_t)0.f;
-                    const half8 v2x = {v2[0], v2[1], v2[2], v2[3], z, z, z, z};
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        floatx4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, pk[t][0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, pk[t][1], a, 0, 0, 0);
-                        o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v2x, pk[t][2], a, 0, 0, 0);
+                    const int i = ip * 2 + t;
+                    floatx4 v;
+                    if constexpr (D == 40) {
+                        v = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, hh ? q1[i] : q0[i], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    } else {
+                        v = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, q0[i], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_16x16x32_f16(kbf, q1[i], v, 0, 0, 0);
                     }
+                    s[t][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k16x, qT[i], v, 0, 0, 0);
                 }
-                // ---- normalise and store: lane (query fr, fq) holds d = dt*16 + fq*4 + 0..3 -------
+            }
+            // ---- softmax over the n_keys keys (base-2 logits: the scale is folded into Wq); P held as the
+            // B operands of the PV product: pk[t][kg] = key blocks {2 kg, 2 kg + 1}, block 4 zero-extended ----
+            half8 pk[2][3];
+            float lsum[2] = {0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r >= kb_last_valid) s[t][4][r] = -INFINITY;
+                float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
+#pragma unroll
+                for (int kb = 1; kb < XA_KB; ++kb)
+                    mx = fmaxf(mx, fmaxf(fmaxf(s[t][kb][0], s[t][kb][1]), fmaxf(s[t][kb][2], s[t][kb][3])));
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+                for (int kb = 0; kb < XA_KB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const half_t ph = (half_t)__builtin_amdgcn_exp2f(s[t][kb][r] - mx);
+                        pk[t][kb >> 1][(kb & 1) * 4 + r] = ph;
+                        if constexpr (!cfg::ONES) lsum[t] += (float)ph;   // the denominator of the ROUNDED numerators
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[t][2][4 + r] = (half_t)0.f;
+                if constexpr (!cfg::ONES) {
+                    lsum[t] += __shfl_xor(lsum[t], 16, 64);
+                    lsum[t] += __shfl_xor(lsum[t], 32, 64);
+                }
+            }
+            if (!v_ready) {   // first use of the V^T image in this launch
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                v_ready = true;
+            }
+            // ---- O^T = V^T P^T (D = 40: row 40 of the image is all ones: the softmax denominator) ----
+            floatx4 o[2][cfg::DT];
+#pragma unroll
+            for (int dt = 0; dt < cfg::DT; ++dt) {
+                const half8 v0 = *reinterpret_cast<const half8*>(vh + dt * 2560 + lane * 16);
+                const half8 v1 = *reinterpret_cast<const half8*>(vh + dt * 2560 + 1024 + lane * 16);
+                const half4 v2 = *reinterpret_cast<const half4*>(vh + dt * 2560 + 2048 + lane * 8);
+                const half_t z = (half_t)0.f;
+                const half8 v2x = {v2[0], v2[1], v2[2], v2[3], z, z, z, z};
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const float l = __shfl(o[t][2][0], 32 + fr, 64);   // O^T row 40 = dt 2, fq 2, element 0
-                    const float inv = __builtin_amdgcn_rcpf(l);
-                    const unsigned off = o_lane + (unsigned)(((ip * 2 + t) * 16 * g.ldo + hh * XA_D) * 2);
+                    floatx4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, pk[t][0], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, pk[t][1], a, 0, 0, 0);
+                    o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v2x, pk[t][2], a, 0, 0, 0);
+                }
+            }
+            // ---- normalise and store: lane (query fr, fq) holds d = dt*16 + fq*4 + 0..3 -------
 #pragma unroll
-                    for (int dt = 0; dt < 3; ++dt) {
-                        half4 v;
+            for (int t = 0; t < 2; ++t) {
+                float l = lsum[t];
+                if constexpr (cfg::ONES) l = __shfl(o[t][2][0], 32 + fr, 64);   // O^T row 40 = dt 2, fq 2, element 0
+                const float inv = __builtin_amdgcn_rcpf(l);
+                const unsigned off = o_lane + (unsigned)(((ip * 2 + t) * 16 * g.ldo + hh * D) * 2);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[t][dt][r] * inv);
-                        // dt 2: only d 32..39 (fq < 2) exist; the other lanes aim past the descriptor (dropped)
-                        const unsigned vo = (dt == 2 && fq >= 2) ? 0xffffff00u : off + dt * 32;
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xu32x2, v), rsO, vo, o_rep, 0);
-                    }
+                for (int dt = 0; dt < cfg::DT; ++dt) {
+                    half4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[t][dt][r] * inv);
+                    // D = 40, dt 2: only d 32..39 (fq < 2) exist; the other lanes aim past the descriptor (dropped)
+                    const unsigned vo = (D == 40 && dt == 2 && fq >= 2) ? 0xffffff00u : off + dt * 32;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(xu32x2, v), rsO, vo, o_rep, 0);
                 }
             }
         }
@@ -396,6 +433,19 @@ __global__ __launch_bounds__(1024) void k_xattn40(XattnArgs g, unsigned a_bytes,
 #endif
 }
 
+template <int D>
+static int xa_launch(const XattnArgs& g, int n_rep, unsigned a_bytes, unsigned w_bytes, unsigned o_bytes, hipStream_t st) {
+    typedef XaCfg<D> cfg;
+    constexpr size_t lds = 2 * (size_t)(cfg::BM + 320) * 128 + (2 * 320 + 2 * cfg::BM) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xattn<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_xattn<D>, dim3(g.M / cfg::BM, n_rep, cfg::C / 320), dim3(1024), lds, st, g, a_bytes, w_bytes, o_bytes);
+    return FD_OK;
+}
+
 extern "C" int fd_xattn_q_f16(const fd_xattn_desc* d, void* stream) {
     if (fd_plan_recording() && d) {
         const fd_xattn_desc dc_ = *d;
@@ -403,43 +453,38 @@ extern "C" int fd_xattn_q_f16(const fd_xattn_desc* d, void* stream) {
     }
     FD_CHECK_ARG(d && d->x && d->wq && d->bias && d->ln_colsum && d->ln_stats && d->k_image && d->v_image && d->out,
                  FD_EINVAL, "fd_xattn_q_f16: null pointer");
-    FD_CHECK_ARG(d->heads == XA_HEADS && d->head_dim == XA_D, FD_ESHAPE,
-                 "fd_xattn_q_f16: 8 heads x 40 only (got %d x %d)", d->heads, d->head_dim);
-    FD_CHECK_ARG(d->M > 0 && d->M % 256 == 0 && d->rows_per_sample > 0 && d->rows_per_sample % 256 == 0 &&
+    FD_CHECK_ARG(xa_supported(d->heads, d->head_dim), FD_ESHAPE,
+                 "fd_xattn_q_f16: 8 heads x 40 or 8 x 80 only (got %d x %d)", d->heads, d->head_dim);
+    const int C = d->heads * d->head_dim, bm = d->head_dim == 40 ? 256 : 128;
+    FD_CHECK_ARG(d->M > 0 && d->M % bm == 0 && d->rows_per_sample > 0 && d->rows_per_sample % bm == 0 &&
                      d->M % d->rows_per_sample == 0,
-                 FD_ESHAPE, "fd_xattn_q_f16: M=%d and rows_per_sample=%d must be multiples of 256", d->M, d->rows_per_sample);
+                 FD_ESHAPE, "fd_xattn_q_f16: M=%d and rows_per_sample=%d must be multiples of %d", d->M, d->rows_per_sample, bm);
     FD_CHECK_ARG(d->n_keys > 64 && d->n_keys <= 80 && d->n_rep >= 1, FD_ESHAPE, "fd_xattn_q_f16: 65..80 keys, n_rep >= 1 (got %d keys)", d->n_keys);
-    FD_CHECK_ARG(d->ldx % 8 == 0 && d->ldw % 8 == 0 && d->ldo % 4 == 0 && d->ldx >= XA_C && d->ldw >= XA_C && d->ldo >= XA_C,
+    FD_CHECK_ARG(d->ldx % 8 == 0 && d->ldw % 8 == 0 && d->ldo % 4 == 0 && d->ldx >= C && d->ldw >= C && d->ldo >= C,
                  FD_ESHAPE, "fd_xattn_q_f16: leading dimensions");
     FD_CHECK_ARG((((uintptr_t)d->x | (uintptr_t)d->wq | (uintptr_t)d->k_image | (uintptr_t)d->v_image | (uintptr_t)d->bias |
                    (uintptr_t)d->ln_colsum | (uintptr_t)d->ln_stats) % 16 == 0) && (uintptr_t)d->out % 8 == 0,
                  FD_ESHAPE, "fd_xattn_q_f16: pointers must be 16-byte aligned");
-    const unsigned long long a_bytes = 2ull * ((unsigned long long)(d->M - 1) * d->ldx + XA_C);
-    const unsigned long long w_bytes = 2ull * ((unsigned long long)(XA_C - 1) * d->ldw + XA_C);
-    FD_CHECK_ARG(a_bytes < 0x7fffffffull, FD_ESHAPE, "fd_xattn_q_f16: hidden-state tensor >= 2 GiB");
+    const unsigned long long a_bytes = 2ull * ((unsigned long long)(d->M - 1) * d->ldx + C);
+    const unsigned long long w_bytes = 2ull * ((unsigned long long)(C - 1) * d->ldw + C);
+    const unsigned long long o_bytes = 2ull * ((unsigned long long)((long long)d->n_rep * d->M - 1) * d->ldo + C);
+    FD_CHECK_ARG(a_bytes < 0x7fffffffull && o_bytes < 0x7fffffffull, FD_ESHAPE, "fd_xattn_q_f16: tensor >= 2 GiB");
     XattnArgs g;
     g.A = (const half_t*)d->x; g.W = (const half_t*)d->wq; g.bias = d->bias; g.colsum = d->ln_colsum;
     g.ln_stats = d->ln_stats; g.kimg = (const char*)d->k_image; g.vimg = (const char*)d->v_image;
     g.O = (half_t*)d->out;
     g.M = d->M; g.lda = d->ldx; g.ldw = d->ldw; g.ldo = d->ldo;
-    g.rows_per_sample = d->rows_per_sample; g.nrep = d->n_rep;
+    g.rows_per_sample = d->rows_per_sample;
     g.samples_per_rep = d->M / d->rows_per_sample; g.n_keys = d->n_keys;
-    constexpr size_t lds = 2 * (size_t)(256 + 320) * 128 + (2 * 320 + 2 * 256) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
-        FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xattn40), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
     hipStream_t st = (hipStream_t)stream;
-    // priced like the two launches it replaces: the q projection (GEMM family would count 2 M 320 320) and the
-    // attention proper (4 B heads Nq Nk d per replica)
-    const double flops = 2.0 * d->M * 320.0 * 320.0 + 4.0 * (double)d->n_rep * d->M * d->n_keys * XA_C;   // q priced once
+    // priced like the two launches it replaces: the q projection (2 M C C, once) and the attention proper
+    // (4 heads Nq Nk d per replica)
+    const double flops = 2.0 * d->M * (double)C * C + 4.0 * (double)d->n_rep * d->M * d->n_keys * C;
     fd_prof_begin(FD_FAMILY_ATTENTION, st, flops);
-    const unsigned long long o_bytes = 2ull * ((unsigned long long)((long long)d->n_rep * d->M - 1) * d->ldo + XA_C);
-    FD_CHECK_ARG(o_bytes < 0x7fffffffull, FD_ESHAPE, "fd_xattn_q_f16: output tensor >= 2 GiB");
-    hipLaunchKernelGGL(k_xattn40, dim3(d->M / 256, d->n_rep), dim3(1024), lds, st, g, (unsigned)a_bytes, (unsigned)w_bytes,
-                       (unsigned)o_bytes);
+    const int rc = d->head_dim == 40 ? xa_launch<40>(g, d->n_rep, (unsigned)a_bytes, (unsigned)w_bytes, (unsigned)o_bytes, st)
+                                     : xa_launch<80>(g, d->n_rep, (unsigned)a_bytes, (unsigned)w_bytes, (unsigned)o_bytes, st);
     fd_prof_end(FD_FAMILY_ATTENTION, st);
-    FD_CHECK_LAUNCH("k_xattn40");
+    if (rc != FD_OK) return rc;
+    FD_CHECK_LAUNCH("k_xattn");
     return FD_OK;
 }

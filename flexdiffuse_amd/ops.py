@@ -441,10 +441,15 @@ class fd_xattn_desc(ctypes.Structure):
                 ('head_dim', c_int32)]
 
 
+def xattn_row_tile(head_dim: int) -> int:
+    '''Rows per workgroup tile of fd_xattn_q_f16 (rows per sample must be a multiple): 256 at head dim 40, 128 at 80.'''
+    return 256 if head_dim == 40 else 128
+
+
 def xattn_supported(heads: int, head_dim: int, n_keys: int, rows_per_sample: int) -> bool:
     '''True when fd_xattn_q_f16 (fused LayerNorm-fold q projection + cross-attention) covers the shape.'''
-    return (os.environ.get('FD_UNET_XATTN', '1') != '0' and rows_per_sample % 256 == 0 and 64 < n_keys <= 80
-            and hip.lib().fd_xattn_image_bytes(heads, head_dim) > 0)
+    return (os.environ.get('FD_UNET_XATTN', '1') != '0' and 64 < n_keys <= 80
+            and hip.lib().fd_xattn_image_bytes(heads, head_dim) > 0 and rows_per_sample % xattn_row_tile(head_dim) == 0)
 
 
 def xattn_pack_kv(k: torch.Tensor, vt: torch.Tensor, samples: int, n_keys: int, heads: int, head_dim: int,

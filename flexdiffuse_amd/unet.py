@@ -248,7 +248,7 @@ class UNet2DConditionModel():
                 a.ctx_img = None
                 realloc = True
             # 8 heads x 40 (the 64x64 level): K / V^T also packed in MFMA fragment order for fd_xattn_q_f16
-            if a.ln_fold and a.q_pre and ops.xattn_supported(a.heads, a.C // a.heads, L, 256):
+            if a.ln_fold and a.q_pre and ops.xattn_supported(a.heads, a.C // a.heads, L, ops.xattn_row_tile(a.C // a.heads)):
                 a.ctx_img = ops.xattn_pack_kv(a.ctx_kv[0], a.ctx_kv[1], Be, L, a.heads, a.C // a.heads, out=a.ctx_img)
             else:
                 a.ctx_img = None
@@ -297,10 +297,10 @@ class UNet2DConditionModel():
         h = ops.gemm(o, a.o1, residual=h, ln_stats_out=st)
         kc, vtc, L = a.ctx_kv
         xt = x.t
-        if a.ctx_img is not None and st is not None and HW % 256 == 0:
+        if a.ctx_img is not None and HW % ops.xattn_row_tile(d) == 0:
             # q projection + cross-attention in one launch (the query matrix never goes to HBM); `rep`
             # context replicas share the queries
-            o = ops.xattn_q(h, a.q2, st, a.ctx_img, HW, L, a.heads, d, n_rep=rep)
+            o = ops.xattn_q(h, a.q2, st if st is not None else ops.ln_row_stats(h), a.ctx_img, HW, L, a.heads, d, n_rep=rep)
         else:
             if a.ln_fold:
                 q2 = ops.gemm(h, a.q2, ln_stats=st if st is not None else ops.ln_row_stats(h))

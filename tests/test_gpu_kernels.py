@@ -443,17 +443,19 @@ def test_gemm_emits_row_stats_of_its_output(dev, M, res):
         ops.gemm(a[:, :K], ops.prep_linear(torch.zeros((640, K)), None, dev), ln_stats_out=st)
 
 
-@pytest.mark.parametrize('B,HW,rep,L', [(2, 4096, 1, 77), (1, 1024, 2, 77), (3, 256, 1, 65), (2, 512, 2, 80)])
-def test_fused_q_projection_cross_attention(dev, B, HW, rep, L):
+@pytest.mark.parametrize('B,HW,rep,L,d', [(2, 4096, 1, 77, 40), (1, 1024, 2, 77, 40), (3, 256, 1, 65, 40), (2, 512, 2, 80, 40),
+                                            (16, 1024, 1, 77, 80), (2, 128, 2, 66, 80), (3, 2304, 1, 77, 80)])
+def test_fused_q_projection_cross_attention(dev, B, HW, rep, L, d):
     '''fd_xattn_q_f16: LayerNorm-fold q projection + softmax(Q K^T) V over a packed 65..80-key context in
-    ONE launch (8 heads x 40) vs (a) the two launches it replaces -- fd_gemm_f16 with ln_stats, then
+    ONE launch (8 heads x 40: 256-row tiles, a head pair per wave; 8 x 80: 128-row tiles, two n-tiles, a head per wave) vs (a) the two launches it replaces -- fd_gemm_f16 with ln_stats, then
     fd_attention_f16 with q_prescaled -- and (b) a torch fp32 reference of LayerNorm -> to_q ->
     attention.  Q is rounded to fp16 identically in both device paths; the attention proper differs in
     MFMA summation order (channel / key permutations inside the fragments) and in the softmax
     reference point (exact row max here, first-tile lazy max there), so (a) is a few fp16 ulps, not
     bit-level.  `rep` > 1: context replicas sharing the queries (the CFG fan-out of the shared prefix).'''
     from flexdiffuse_amd import ops
-    C, heads, d = 320, 8, 40
+    heads = 8
+    C = heads * d
     M = B * HW
     g = torch.Generator().manual_seed(B * HW + rep + L)
     x = (torch.randn((M, C), generator=g) * (0.5 + torch.rand((M, 1), generator=g) * 2) +
@@ -493,8 +495,8 @@ def test_fused_q_projection_cross_attention(dev, B, HW, rep, L):
         assert e <= 2e-2 * float(want.abs().max()), (r, e, float(want.abs().max()))
     if rep == 2:   # the replicas really saw different contexts
         assert float((got[:M] - got[M:]).abs().max()) > 0.05
-    assert not ops.xattn_supported(8, 80, L, HW) and not ops.xattn_supported(heads, d, 64, HW)
-    assert not ops.xattn_supported(heads, d, L, 64)
+    assert not ops.xattn_supported(8, 64, L, HW) and not ops.xattn_supported(heads, d, 64, HW)
+    assert not ops.xattn_supported(heads, d, L, 64) and not ops.xattn_supported(5, 64, L, HW)
 
 
 @pytest.mark.parametrize('B,H,Cin,Cx', [(16, 64, 320, 640), (4, 32, 640, 960), (16, 16, 1280, 2560), (16, 8, 1280, 2560),

@@ -1,0 +1,71 @@
+'''Per-launch timing of ONE CFG UNet forward (headline shape) through the eager front: every C-ABI call is bracketed by two
+events on the launch stream; prints the launches grouped by (entry point, shape) with count, mean us and share.'''
+import sys, os, ctypes, collections; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from flexdiffuse_amd import build, hip, ops
+from flexdiffuse_amd.unet import UNet2DConditionModel
+dev = torch.device('cuda:0')
+sds = build.synthetic_state_dicts('sd15', seed=0, parts=('unet',))
+unet = UNet2DConditionModel(sds['unet'], build.configs('sd15')[0], dev)
+B = 8
+x = torch.randn((B, 4, 64, 64), device=dev)
+ctx = torch.randn((2 * B, 77, 768), device=dev).half()
+for i in range(3):
+    unet.forward_nhwc(x, 400 - i, ctx, rep=2)
+torch.cuda.synchronize()
+recs = []
+orig = hip.call
+
+
+def describe(name, args):
+    a0 = args[0]
+    obj = getattr(a0, '_obj', None)
+    if isinstance(obj, ops.fd_gemm_desc):
+        d = obj
+        kind = 'conv' if d.conv else 'gemm'
+        extra = ''
+        if d.conv:
+            extra = f' {d.kh}x{d.kw} s{d.stride}' + (' up' if d.upsample2x == 1 else ' phases' if d.upsample2x == 2 else '')
+        if d.K2: extra += f' +K2 {d.K2}'
+        if d.trans_out: extra += ' V^T'
+        if d.act == 4: extra += ' GEGLU'
+        if d.residual: extra += ' +res'
+        if d.ln_stats: extra += ' LNfold'
+        if d.ln_stats_out: extra += ' stats'
+        return f'{kind} M{d.M} N{d.N} K{d.K}{extra}' + (f' x{d.batch}' if d.batch > 1 else '')
+    if isinstance(obj, ops.fd_attention_desc):
+        d = obj
+        return f'attention B{d.batch} h{d.heads} nq{d.n_q} nk{d.n_k} d{d.head_dim}'
+    if isinstance(obj, ops.fd_xattn_desc):
+        d = obj
+        return f'xattn_q M{d.M} rep{d.n_rep}'
+    if name.startswith('fd_groupnorm'):
+        return f'groupnorm B{args[6]} HW{args[7]} C{args[8]} silu{args[11]}'
+    if name == 'fd_ln_row_stats_f16':
+        return f'ln_row_stats rows{args[2]} C{args[3]}'
+    if name == 'fd_copy2d_f16':
+        return f'copy2d rows{args[4]} cols{args[5]}'
+    return name
+
+
+def traced(name, *args):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    orig(name, *args)
+    e1.record()
+    recs.append((describe(name, args), e0, e1))
+
+
+hip.call = traced
+unet.forward_nhwc(x, 390, ctx, rep=2)
+torch.cuda.synchronize()
+hip.call = orig
+agg = collections.OrderedDict()
+for k, e0, e1 in recs:
+    us = 1e3 * e0.elapsed_time(e1)
+    n, t = agg.get(k, (0, 0.0))
+    agg[k] = (n + 1, t + us)
+tot = sum(t for _, t in agg.values())
+print(f'{len(recs)} launches, {tot / 1e3:.2f} ms bracketed (each bracket adds ~3-6 us)')
+for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f'{100 * t / tot:5.1f} %  {n:3d} x {t / n:8.1f} us  {k}')
