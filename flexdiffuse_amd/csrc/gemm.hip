@@ -303,10 +303,16 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
                         s1 += p[0];
                         s2 += p[1];
                     }
-                    const float mean = s1 * inv_n;
-                    const float var = fmaxf(fmaf(-mean, mean, s2 * inv_n), 0.f);
-                    const float rstd = rsqrtf(var + g.ln_eps);
-                    *reinterpret_cast<floatx2*>(g.ln_stats_out + 2 * (size_t)(m0 + tr)) = floatx2{rstd, -mean * rstd};
+                    if constexpr (WN_ == 2) {   // the 160-wide tiles (the 256x320 tile, WN_ == 4, spans its row)
+                        // the row spans several n-tiles: this tile's raw (sum, sum of squares) goes to slab `tile_n` of
+                        // ln_stats_out [N / BN][M][2]; fd_ln_finalize_stats_f32 combines the slabs in a fixed order
+                        *reinterpret_cast<floatx2*>(g.ln_stats_out + 2 * ((size_t)(col0 / (NI * 16 * WN_)) * g.M + m0 + tr)) = floatx2{s1, s2};
+                    } else {
+                        const float mean = s1 * inv_n;
+                        const float var = fmaxf(fmaf(-mean, mean, s2 * inv_n), 0.f);
+                        const float rstd = rsqrtf(var + g.ln_eps);
+                        *reinterpret_cast<floatx2*>(g.ln_stats_out + 2 * (size_t)(m0 + tr)) = floatx2{rstd, -mean * rstd};
+                    }
                 }
             }
         }
@@ -1092,12 +1098,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     if constexpr (EPI == 0 || EPI == 7)   // 7: the generic epilogue with the LayerNorm fold compiled in
         gemm_epilogue<BM, BN, TRANS, WM, WN, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
                                                        b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr, kslice);
-    else if constexpr (EPI == 8 || EPI == 9)   // lean + LayerNorm statistics of the written rows (N == BN); the
-        // exchange buffer reuses stage 0 (the K loop ended with a barrier: the stages are dead)
+    else if constexpr (EPI == 8 || EPI == 9) {   // lean + LayerNorm statistics of the written rows; the
+        // exchange buffer reuses stage 0 (the 2-stage K loop ends with a barrier: the stages are dead; the 3-stage loop
+        // has its barrier at the TOP of an iteration, so the last K-tile may still be read: one more barrier)
+        if constexpr (NS == 3) __syncthreads();
         gemm_epilogue_fast<MI, NI, FD_ACT_NONE, EPI == 9, true, false, true, WN>(
             g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN),
             reinterpret_cast<float*>(smem), wm * WTM + fr, wn, m0);
-    else
+    } else
         gemm_epilogue_fast<MI, NI, (EPI == 3 || EPI == 6) ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, true, (EPI == 5 || EPI == 6)>(
             g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN));
 #endif
@@ -1430,7 +1438,7 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         const int occ = (BM >= 256 || lds > 80 * 1024) ? 1 : (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);  // workgroups / CU
         const int slots = 256 * occ;
         const int nkt = (g.K + BK - 1) / BK / g.split_k;
-        const bool persistent = NS == 2 && BN != 320 && g.K2 == 0 && !g.phase && (g_persist_mode == 2 ||
+        const bool persistent = NS == 2 && BN != 320 && g.K2 == 0 && !g.phase && !g.ln_stats_out && (g_persist_mode == 2 ||
                                 (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots));
         if constexpr (EPI >= 1 && EPI <= 3) {
             // the persistent loop does not stage the per-sample bias: generic epilogue there
@@ -1501,12 +1509,13 @@ static int launch_epi(GemmArgs& g, int batch, hipStream_t st) {
     if (g.ln_stats_out) {
         // row statistics of the output: only tiles that span the whole row (N == BN), lean epilogue
         if constexpr ((ALLOW & 256) != 0) {
-            if (full && g.N == BN && g.act == FD_ACT_NONE && g.mode != MODE_CONV && !g.ln_stats && !g.bias2) {
+            // (the 256x320 tile finalises its rows: N == BN; the 160-wide tiles write per-n-tile partial sums)
+            if (full && (BN != 320 || g.N == BN) && g.act == FD_ACT_NONE && g.mode != MODE_CONV && !g.ln_stats && !g.bias2) {
                 if (g.res && (g.ldr & 3) == 0) return launch_mode<BM, BN, false, false, WM, NS, WN, 9>(g, batch, st);
                 if (!g.res) return launch_mode<BM, BN, false, false, WM, NS, WN, 8>(g, batch, st);
             }
         }
-        fd_set_error("fd_gemm_f16: ln_stats_out needs N == 320, M %% 256 == 0, a plain or residual linear GEMM");
+        fd_set_error("fd_gemm_f16: ln_stats_out needs full tiles of a tile shape with a statistics epilogue, a plain or residual linear GEMM");
         return FD_ESHAPE;
     }
     if (full && g.ln_stats) {
@@ -1541,9 +1550,11 @@ static int launch_epi(GemmArgs& g, int batch, hipStream_t st) {
 // take those away).  Callers that get 0 run fd_ln_row_stats_f16 on the output instead.
 extern "C" int fd_gemm_can_emit_row_stats(int M, int N, int K, int ldc, int ldr) {
     if (!(g_use_dma && g_fast_epi && g_bias_lds)) return 0;
-    if (N != 320 || M <= 0 || M % 256 != 0 || K <= 0 || K % 8 != 0) return 0;
+    if (M <= 0 || K <= 0 || K % 8 != 0) return 0;
+    if (N == 320 ? M % 256 != 0 : (N <= 320 || N % 160 != 0 || M % 128 != 0)) return 0;
     if (ldc < N || (ldc & 7) != 0 || (ldr != 0 && (ldr < N || (ldr & 3) != 0))) return 0;
-    return 2ull * ((unsigned long long)(M - 1) * (unsigned long long)ldc + N) < 0x7fffffffull ? 1 : 0;
+    if (2ull * ((unsigned long long)(M - 1) * (unsigned long long)ldc + N) >= 0x7fffffffull) return 0;
+    return N == 320 ? 1 : N / 160;   // n-tiles of partial sums the caller must provide and finalise (1: finalised in place)
 }
 
 extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
@@ -1739,12 +1750,18 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     if (d->tile) best_tile = d->tile;
     if (d->split_k > 0) best_split = d->split_k;
     if (g.ln_stats) best_split = 1;   // the split-K finish kernel does not know the fold
-    if (d->ln_stats_out) {            // the 256x320 tile spans the whole row: it can finalise the statistics
-        FD_CHECK_ARG(g.N == 320 && g.M % 256 == 0 && !d->conv && !d->trans_out && !d->out_f32, FD_ESHAPE,
-                     "fd_gemm_f16: ln_stats_out needs N == 320 and M %% 256 == 0 (got M=%d N=%d)", g.M, g.N);
+    if (d->ln_stats_out) {
+        // N == 320: the 256x320 tile spans the whole row and finalises (rstd, -mean rstd) itself.  N a larger multiple of
+        // 160: the 160-wide tiles write raw per-n-tile partial sums [N / 160][M][2] for fd_ln_finalize_stats_f32.
+        const bool whole = g.N == 320 && g.M % 256 == 0;
+        const bool parts = g.N > 320 && g.N % 160 == 0 && g.M % 128 == 0;
+        FD_CHECK_ARG((whole || parts) && !d->conv && !d->trans_out && !d->out_f32 && batch == 1, FD_ESHAPE,
+                     "fd_gemm_f16: ln_stats_out needs N == 320 with M %% 256 == 0, or N %% 160 == 0 with M %% 128 == 0 (got M=%d N=%d)", g.M, g.N);
         g.ln_stats_out = d->ln_stats_out;
         g.ln_eps = d->ln_eps > 0.f ? d->ln_eps : 1e-5f;
-        best_tile = 16;
+        if (whole) best_tile = 16;
+        else if (best_tile != 13 && best_tile != 12 && best_tile != 20) best_tile = (g.M % 256 == 0 && g.M > 4096) ? 13 : 12;
+        if (best_tile == 13 && g.M % 256 != 0) best_tile = 12;
         best_split = 1;
     }
     {
@@ -1809,13 +1826,13 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         case 9: rc = launch_epi<128, 160, 4, 2, 2, 38>(g, batch, st); break;    // 8 waves, 32x80 wave tiles
         case 10: rc = launch_epi<128, 128, 4, 2, 2, 110>(g, batch, st); break;
         case 11: rc = launch<128, 64, false, 4>(g, batch, st); break;
-        case 12: rc = launch_epi<128, 160, 8, 2, 2, 38>(g, batch, st); break;   // 16 waves, 16x80 wave tiles
-        case 13: rc = launch_epi<256, 160, 8, 2, 2, 38>(g, batch, st); break;   // 16 waves, 32x80 wave tiles
+        case 12: rc = launch_epi<128, 160, 8, 2, 2, 38 + 256>(g, batch, st); break;   // 16 waves, 16x80 wave tiles
+        case 13: rc = launch_epi<256, 160, 8, 2, 2, 38 + 256>(g, batch, st); break;   // 16 waves, 32x80 wave tiles
         case 14: rc = launch_epi<256, 128, 8, 2, 2, 110>(g, batch, st); break;   // 16 waves, 32x64 wave tiles
         case 8: rc = launch<256, 128, false, 4, 3>(g, batch, st); break;
         case 15: rc = launch_epi<256, 256, 4, 2, 4, 110>(g, batch, st); break;  // 16 waves, 64x64 wave tiles
         case 16: rc = launch_epi<256, 320, 4, 2, 4, 294>(g, batch, st); break;  // 16 waves, 64x80 wave tiles
-        case 20: rc = launch_epi<128, 160, 4, 3, 2, 38>(g, batch, st); break;   // tile 9 with 3 LDS stages
+        case 20: rc = launch_epi<128, 160, 4, 3, 2, 38 + 256>(g, batch, st); break;   // tile 9 with 3 LDS stages
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }
     if (rc == FD_OK && g.split_k > 1) {

@@ -54,6 +54,7 @@ _SIGNATURES = {
     'fd_groupnorm_nhwc_ld_f16': (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'fd_layernorm_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'fd_ln_row_stats_f16': (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
+    'fd_ln_finalize_stats_f32': (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
     'fd_softmax_rows_f16': (c_int, [P, c_int, c_int, c_int, c_float, P]),
     'fd_nchw_f32_to_nhwc_f16': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'fd_nhwc_f32_to_nchw_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P]),

@@ -126,12 +126,22 @@ def prep_linear_ln(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tens
     return lw
 
 
-def can_emit_row_stats(M: int, N: int, K: int = 320, ldc: int = 0, ldr: int = 0) -> bool:
-    '''True when fd_gemm_f16 can write the LayerNorm statistics of its output rows itself
-    (fd_gemm_desc.ln_stats_out: one 256x320 tile spans the whole row, lean epilogue on the LDS-DMA
-    path).  The library answers, so its A/B switches (FD_GEMM_FAST_EPI=0, FD_GEMM_BIAS_LDS=0,
-    FD_GEMM_NO_DMA) degrade to the separate statistics pass instead of an FD_ESHAPE.'''
-    return bool(hip.lib().fd_gemm_can_emit_row_stats(M, N, K, ldc or N, ldr))
+def can_emit_row_stats(M: int, N: int, K: int = 320, ldc: int = 0, ldr: int = 0) -> int:
+    '''How fd_gemm_f16 can write the LayerNorm statistics of its output rows itself (fd_gemm_desc.ln_stats_out):
+    0 not at all (run ln_row_stats on the output), 1 the finished pairs (N == 320: one 256x320 tile spans the row),
+    k > 1: k slabs of raw partial sums [k][M][2] that ln_finalize_stats combines.  The library answers, so its A/B
+    switches (FD_GEMM_FAST_EPI=0, FD_GEMM_BIAS_LDS=0, FD_GEMM_NO_DMA) degrade to the separate statistics pass.'''
+    if N != 320 and os.environ.get('FD_UNET_LN_PARTS', '1') == '0':
+        return 0
+    return int(hip.lib().fd_gemm_can_emit_row_stats(M, N, K, ldc or N, ldr))
+
+
+def ln_finalize_stats(parts: torch.Tensor, N: int, eps: float = 1e-5) -> torch.Tensor:
+    '''[k][M][2] partial sums of a stats-emitting GEMM -> [M][2] (rstd, -mean rstd).'''
+    k, M, _ = parts.shape
+    out = _empty((M, 2), torch.float32, parts)
+    hip.call('fd_ln_finalize_stats_f32', parts.data_ptr(), out.data_ptr(), M, N, k, eps, hip.stream())
+    return out
 
 
 def ln_row_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
@@ -306,7 +316,7 @@ def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[to
         assert w.colsum is not None and ln_stats.shape == (M, 2)
         d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), w.colsum.data_ptr()
     if ln_stats_out is not None:  # the GEMM also writes the LayerNorm statistics of its output rows
-        assert ln_stats_out.shape == (M, 2) and ln_stats_out.dtype == torch.float32
+        assert ln_stats_out.shape[-2:] == (M, 2) and ln_stats_out.dtype == torch.float32 and ln_stats_out.is_contiguous()
         d.ln_stats_out, d.ln_eps = ln_stats_out.data_ptr(), ln_eps
     _sched(d, a.device)
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())

@@ -278,13 +278,25 @@ class UNet2DConditionModel():
         h = ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False)
         # LayerNorm fold: the GEMM that PRODUCES a LayerNorm input also writes its row statistics where one
         # tile spans the row (C == 320: the 64x64 level); elsewhere one read-only statistics pass
-        emit = a.ln_fold and a.ln_emit and ops.can_emit_row_stats(B * HW, C)
-        mkst = lambda rows: torch.empty((rows, 2), dtype=torch.float32, device=x.t.device) if emit else None
+        # (C == 320: finished pairs; wider rows: raw partial sums per 160-column tile + a tiny finalise launch)
+        emit = (a.ln_fold and a.ln_emit) and ops.can_emit_row_stats(B * HW, C, C)
+
+        def mkst(rows):
+            k = emit and ops.can_emit_row_stats(rows, C, C)
+            if not k:
+                return None
+            return torch.empty((rows, 2) if k == 1 else (k, rows, 2), dtype=torch.float32, device=x.t.device)
+
+        def fin(st, hh):
+            '''(rstd, -mean rstd) of the rows of hh: emitted by its producer, finalised from its partial sums, or
+            from one read-only pass.'''
+            if st is None:
+                return ops.ln_row_stats(hh)
+            return st if st.dim() == 2 else ops.ln_finalize_stats(st, C)
         st = mkst(B * HW)
         h = ops.gemm(h.t, a.proj_in, ln_stats_out=st)
         if a.ln_fold:
-            if st is None:
-                st = ops.ln_row_stats(h)
+            st = fin(st, h)
             qk = ops.gemm(h, a.qk1, ln_stats=st)
             vt = ops.gemm_vt(h, a.v1, B, HW, (HW + 7) // 8 * 8, ln_stats=st)
         else:
@@ -300,10 +312,10 @@ class UNet2DConditionModel():
         if a.ctx_img is not None and HW % ops.xattn_row_tile(d) == 0:
             # q projection + cross-attention in one launch (the query matrix never goes to HBM); `rep`
             # context replicas share the queries
-            o = ops.xattn_q(h, a.q2, st if st is not None else ops.ln_row_stats(h), a.ctx_img, HW, L, a.heads, d, n_rep=rep)
+            o = ops.xattn_q(h, a.q2, fin(st, h), a.ctx_img, HW, L, a.heads, d, n_rep=rep)
         else:
             if a.ln_fold:
-                q2 = ops.gemm(h, a.q2, ln_stats=st if st is not None else ops.ln_row_stats(h))
+                q2 = ops.gemm(h, a.q2, ln_stats=fin(st, h))
             else:
                 q2 = ops.gemm(ops.layernorm(h, *a.ln[1]), a.q2)
             if rep == 1:
@@ -318,7 +330,7 @@ class UNet2DConditionModel():
         st = mkst(B * HW)
         h = ops.gemm(o, a.o2, residual=h, ln_stats_out=st)
         if a.ln_fold:
-            f = ops.gemm(h, a.ff1, act=ops.ACT_GEGLU, ln_stats=st if st is not None else ops.ln_row_stats(h))
+            f = ops.gemm(h, a.ff1, act=ops.ACT_GEGLU, ln_stats=fin(st, h))
         else:
             f = ops.gemm(ops.layernorm(h, *a.ln[2]), a.ff1, act=ops.ACT_GEGLU)
         if a.ffp is not None:

@@ -189,8 +189,11 @@ typedef struct fd_gemm_desc {
     const float* ln_colsum; /* fp32 [N] */
     /* Producer side of the fold: also write ln_stats_out[m] = (rstd_m, -mean_m rstd_m) of the OUTPUT rows
      * (LayerNorm over the N columns, eps ln_eps, statistics of the fp16-rounded values), so that the next
-     * GEMM can take them as its ln_stats without a separate statistics pass.  Only where one workgroup
-     * tile spans the whole row: N == 320, M % 256 == 0, linear, plain or residual epilogue. NULL = off. */
+     * GEMM can take them as its ln_stats without a separate statistics pass.  N == 320, M % 256 == 0: one workgroup
+     * tile spans the row and writes the finished pair.  N a larger multiple of 160, M % 128 == 0: ln_stats_out is
+     * [N / 160][M][2] RAW partial sums (sum, sum of squares per 160-column tile), to be combined by
+     * fd_ln_finalize_stats_f32.  fd_gemm_can_emit_row_stats returns the slab count (0: not possible, 1: finished).
+     * Linear, plain or residual epilogue. NULL = off. */
     float* ln_stats_out;
     float ln_eps;
     /* APPENDED phase: after the K columns of the GEMM / convolution the same K loop runs K2 more columns over the plain
@@ -206,8 +209,9 @@ typedef struct fd_gemm_desc {
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);
-/* 1 when fd_gemm_f16 will honour ln_stats_out for an [M][N] fp16 output (row stride ldc, residual row
- * stride ldr or 0) with the library's current settings, else 0: then run fd_ln_row_stats_f16 on the output. */
+/* > 0 when fd_gemm_f16 will honour ln_stats_out for an [M][N] fp16 output (row stride ldc, residual row stride ldr
+ * or 0) with the library's current settings: 1 = the finished (rstd, -mean rstd) pairs, k > 1 = k slabs of partial
+ * sums for fd_ln_finalize_stats_f32; 0: run fd_ln_row_stats_f16 on the output instead. */
 int fd_gemm_can_emit_row_stats(int M, int N, int K, int ldc, int ldr);
 
 /* Flash attention forward (scores never leave registers).  Q [B][n_q][ldq], K [B][n_k][ldk]
@@ -281,6 +285,9 @@ int fd_layernorm_f16(const void* x, void* y, const float* gamma, const float* be
 /* Per-row LayerNorm statistics of fp16 x [rows][ldx] (exact two-pass, fp32): stats[row] = (rstd,
  * -mean * rstd) with rstd = 1 / sqrt(var + eps); consumed by fd_gemm_desc.ln_stats. */
 int fd_ln_row_stats_f16(const void* x, float* stats, int rows, int C, int ldx, float eps, void* stream);
+/* partials [n_tiles][M][2] (fd_gemm_desc.ln_stats_out of an N > 320 producer) -> stats [M][2] = (rstd, -mean rstd)
+ * over the N columns, eps as fd_ln_row_stats_f16 (one-pass E[x^2] - mean^2 in fp32, fixed summation order). */
+int fd_ln_finalize_stats_f32(const float* partials, float* stats, int M, int N, int n_tiles, float eps, void* stream);
 /* In-place softmax(scale * x) over the first N columns of fp16 x [rows][ld]. */
 int fd_softmax_rows_f16(void* x, int rows, int N, int ld, float scale, void* stream);
 

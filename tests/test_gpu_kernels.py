@@ -438,9 +438,9 @@ def test_gemm_emits_row_stats_of_its_output(dev, M, res):
     # one-pass E[x^2] - mean^2 in fp32 vs the exact two-pass: relative 1e-4 on rstd, absolute 1e-4 on -mean rstd
     assert float(((st[:, 0] - ref[:, 0]).abs() / ref[:, 0]).max()) < 2e-4
     assert float((st[:, 1] - ref[:, 1]).abs().max()) < 2e-4 * max(1.0, float(ref[:, 1].abs().max()))
-    assert not ops.can_emit_row_stats(M, 640)
+    assert ops.can_emit_row_stats(M, 640) == 4 and not ops.can_emit_row_stats(M, 328) and not ops.can_emit_row_stats(M + 8, 640)
     with pytest.raises(ValueError):
-        ops.gemm(a[:, :K], ops.prep_linear(torch.zeros((640, K)), None, dev), ln_stats_out=st)
+        ops.gemm(a[:, :K], ops.prep_linear(torch.zeros((328, K)), None, dev), ln_stats_out=st)
 
 
 @pytest.mark.parametrize('B,HW,rep,L,d', [(2, 4096, 1, 77, 40), (1, 1024, 2, 77, 40), (3, 256, 1, 65, 40), (2, 512, 2, 80, 40),
@@ -588,3 +588,31 @@ def test_upsample_conv_phase_decomposition(dev, B, H, Cin, Cout):
     assert float((gotf - want).abs().mean()) <= 1.2 * float((old - want).abs().mean()) + 1e-5
     assert float(buf[:, Cout:].abs().max()) == 0.0           # nothing written past the view
     assert not ops.up_phases_supported(1024, Cout, Cin)      # too few rows: stays on the fused-upsample conv
+
+
+@pytest.mark.parametrize('M,N,K,res', [(16384, 640, 640, True), (4096, 1280, 1280, True), (4096, 1280, 1280, False),
+                                       (1024, 1280, 1280, True), (16384, 640, 640, False), (128, 480, 320, True)])
+def test_gemm_emits_partial_row_stats_for_wide_rows(dev, M, N, K, res):
+    '''fd_gemm_desc.ln_stats_out with N > 320: the 160-wide tiles write raw (sum, sum of squares) per n-tile,
+    fd_ln_finalize_stats_f32 combines them -> the same (rstd, -mean rstd) as fd_ln_row_stats_f16 on the stored rows
+    (one-pass E[x^2] - mean^2 in fp32 vs exact two-pass: 2e-4), and the output itself equals the launch without
+    statistics up to tile-choice rounding.  Shapes: the UNet's 32x32 / 16x16 / 8x8-level producers (tiles 13, 20, 12).'''
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn((M, K), generator=g).half().to(dev)
+    w = ops.prep_linear(torch.randn((N, K), generator=g) * K ** -0.5, torch.randn(N, generator=g) * 0.5, dev)
+    r = (torch.randn((M, N), generator=g) * 2 + torch.randn((M, 1), generator=g) * 3).half().to(dev) if res else None
+    k = ops.can_emit_row_stats(M, N, K)
+    assert k == N // 160
+    parts = torch.full((k, M, 2), float('nan'), dtype=torch.float32, device=dev)
+    out = ops.gemm(a, w, residual=r, ln_stats_out=parts)
+    assert bool(torch.isfinite(parts).all())
+    st = ops.ln_finalize_stats(parts, N)
+    plain = ops.gemm(a, w, residual=r)
+    assert float((out.float() - plain.float()).abs().max()) <= 2e-3 * float(plain.float().abs().max())
+    ref = ops.ln_row_stats(out)
+    assert float(((st[:, 0] - ref[:, 0]).abs() / ref[:, 0]).max()) < 2e-4
+    assert float((st[:, 1] - ref[:, 1]).abs().max()) < 2e-4 * max(1.0, float(ref[:, 1].abs().max()))
+    # the slabs really are per-tile sums of the stored values
+    x = out.float()
+    assert torch.allclose(parts[1, :, 0], x[:, 160:320].sum(1), rtol=1e-4, atol=1e-2)

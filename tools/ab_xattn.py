@@ -5,7 +5,7 @@ import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from flexdiffuse_amd import ops
 dev = torch.device('cuda:0')
-C, heads, d, L = 320, 8, 40, 77
+heads, L = 8, 77
 
 
 def timeit(fn, n=30):
@@ -19,7 +19,8 @@ def timeit(fn, n=30):
     return 1e3 * e0.elapsed_time(e1) / n
 
 
-for B, HW, rep in ((16, 4096, 1), (8, 4096, 2), (4, 9216, 1)):
+for B, HW, rep, d in ((16, 4096, 1, 40), (8, 4096, 2, 40), (4, 9216, 1, 40), (16, 1024, 1, 80), (4, 2304, 1, 80)):
+    C = heads * d
     M = B * HW
     g = torch.Generator().manual_seed(1)
     x = (torch.randn((M, C), generator=g) * 1.3 + torch.randn((M, 1), generator=g)).half().to(dev)
@@ -43,5 +44,5 @@ for B, HW, rep in ((16, 4096, 1), (8, 4096, 2), (4, 9216, 1)):
     t_f = timeit(lambda: ops.xattn_q(x, lw, st, img, HW, L, heads, d, n_rep=rep, out=out))
     t_p = timeit(lambda: ops.xattn_pack_kv(kd, vtd, rep * B, L, heads, d, out=img))
     bytes_f = 2 * M * C + 2 * rep * M * C
-    print(f'B {B} HW {HW} rep {rep}: q-proj {t_q:.1f} us, q-proj + attention {t_u:.1f} us, fused {t_f:.1f} us '
+    print(f'd {d} B {B} HW {HW} rep {rep}: q-proj {t_q:.1f} us, q-proj + attention {t_u:.1f} us, fused {t_f:.1f} us '
           f'({bytes_f / t_f / 1e6:.2f} TB/s over x read + out write), pack (once per context) {t_p:.1f} us')
