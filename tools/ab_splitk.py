@@ -31,7 +31,8 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
         out.append(f'{H}x{H} {Cin}->{Cout}: {us:.1f} us ({2 * B * H * H * Cout * 9 * Cin / us / 1e6:.0f} TF) #{h}')
     print('   ' + ' | '.join(out), flush=True)
     sys.exit(0)
-for arm in ('FD_GEMM_SK_FLAT=1', 'FD_GEMM_SK_FLAT=0') * 2:
-    k, v = arm.split('=')
+# arms: "VAR=val[,VAR2=val2]" per argument (default: the flat-grid A/B), e.g.  python tools/ab_splitk.py FD_GEMM_PF=0 FD_GEMM_PF=2
+for arm in tuple(sys.argv[1:] or ('FD_GEMM_SK_FLAT=1', 'FD_GEMM_SK_FLAT=0')) * 2:
     print(arm, flush=True)
-    subprocess.run([sys.executable, os.path.abspath(__file__), '--child'], env=dict(os.environ, **{k: v}), check=False)
+    subprocess.run([sys.executable, os.path.abspath(__file__), '--child'],
+                   env=dict(os.environ, **dict(kv.split('=', 1) for kv in arm.split(','))), check=False)

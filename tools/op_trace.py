@@ -32,7 +32,8 @@ def describe(name, args):
         if d.residual: extra += ' +res'
         if d.ln_stats: extra += ' LNfold'
         if d.ln_stats_out: extra += ' stats'
-        return f'{kind} M{d.M} N{d.N} K{d.K}{extra}' + (f' x{d.batch}' if d.batch > 1 else '')
+        fl = 2.0 * d.M * d.N * (d.K + d.K2) * max(d.batch, 1)
+        return f'{kind} M{d.M} N{d.N} K{d.K}{extra}' + (f' x{d.batch}' if d.batch > 1 else '') + f' #GF{fl / 1e9:.2f}'
     if isinstance(obj, ops.fd_attention_desc):
         d = obj
         return f'attention B{d.batch} h{d.heads} nq{d.n_q} nk{d.n_k} d{d.head_dim}'
@@ -67,5 +68,7 @@ for k, e0, e1 in recs:
     agg[k] = (n + 1, t + us)
 tot = sum(t for _, t in agg.values())
 print(f'{len(recs)} launches, {tot / 1e3:.2f} ms bracketed (each bracket adds ~3-6 us)')
-for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
-    print(f'{100 * t / tot:5.1f} %  {n:3d} x {t / n:8.1f} us  {k}')
+for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
+    gf = float(k.split('#GF')[1]) if '#GF' in k else 0.0   # MFMA work issued (the parity upsample: 4/9 of the algorithmic count)
+    tf = f'  {gf / (t / n) * 1e3:6.0f} TF/s, {t - n * gf * 1e3 / 1100:7.0f} us above 1100 TF/s' if gf else ''
+    print(f'{100 * t / tot:5.1f} %  {n:3d} x {t / n:8.1f} us  {k.split(" #GF")[0]}{tf}')
