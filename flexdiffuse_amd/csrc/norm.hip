@@ -609,14 +609,28 @@ __global__ __launch_bounds__(256) void k_softmax_rows(half_t* __restrict__ x, in
 // ---- LayerNorm statistics from per-n-tile partial sums (fd_gemm_desc.ln_stats_out with N > 320) -----------------
 // parts [n_tiles][M][2] = (sum, sum of squares) of each row over one 160-column tile of the fp16 values the producing
 // GEMM stored; combined in a fixed order -> stats [M][2] = (rstd, -mean rstd), the form fd_gemm_desc.ln_stats takes.
+// NT = compile-time slab count (the loads of all slabs are issued together; a run-time trip count compiles to one
+// dependent load / wait / add round trip per slab: 5 us for 8 slabs), 0 = any count.
+template <int NT>
 __global__ void k_ln_finalize(const float* __restrict__ parts, float* __restrict__ stats, int M, int nt, float inv_n, float eps) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     float s1 = 0.f, s2 = 0.f;
-    for (int t = 0; t < nt; ++t) {
-        const floatx2 p = *reinterpret_cast<const floatx2*>(parts + 2 * ((size_t)t * M + m));
-        s1 += p[0];
-        s2 += p[1];
+    if constexpr (NT > 0) {
+        floatx2 p[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) p[t] = *reinterpret_cast<const floatx2*>(parts + 2 * ((size_t)t * M + m));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {   // fixed order: the same sums whatever the launch shape
+            s1 += p[t][0];
+            s2 += p[t][1];
+        }
+    } else {
+        for (int t = 0; t < nt; ++t) {
+            const floatx2 p = *reinterpret_cast<const floatx2*>(parts + 2 * ((size_t)t * M + m));
+            s1 += p[0];
+            s2 += p[1];
+        }
     }
     const float mean = s1 * inv_n;
     const float var = fmaxf(fmaf(-mean, mean, s2 * inv_n), 0.f);
@@ -627,8 +641,16 @@ __global__ void k_ln_finalize(const float* __restrict__ parts, float* __restrict
 extern "C" int fd_ln_finalize_stats_f32(const float* partials, float* stats, int M, int N, int n_tiles, float eps, void* stream) {
     FD_PLAN(fd_ln_finalize_stats_f32(partials, stats, M, N, n_tiles, eps, fd_s_));
     FD_CHECK_ARG(partials && stats && M > 0 && N > 0 && n_tiles >= 1 && n_tiles <= 64, FD_EINVAL, "fd_ln_finalize_stats_f32: args");
-    hipLaunchKernelGGL(k_ln_finalize, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, stats, M, n_tiles,
-                       1.0f / (float)N, eps > 0.f ? eps : 1e-5f);
+    const dim3 grid((M + 63) / 64), block(64);   // one wave per workgroup: 16384 rows spread over all 256 CUs
+    const float inv_n = 1.0f / (float)N, e = eps > 0.f ? eps : 1e-5f;
+    hipStream_t st = (hipStream_t)stream;
+    switch (n_tiles) {
+        case 2: hipLaunchKernelGGL(k_ln_finalize<2>, grid, block, 0, st, partials, stats, M, n_tiles, inv_n, e); break;
+        case 3: hipLaunchKernelGGL(k_ln_finalize<3>, grid, block, 0, st, partials, stats, M, n_tiles, inv_n, e); break;
+        case 4: hipLaunchKernelGGL(k_ln_finalize<4>, grid, block, 0, st, partials, stats, M, n_tiles, inv_n, e); break;
+        case 8: hipLaunchKernelGGL(k_ln_finalize<8>, grid, block, 0, st, partials, stats, M, n_tiles, inv_n, e); break;
+        default: hipLaunchKernelGGL(k_ln_finalize<0>, grid, block, 0, st, partials, stats, M, n_tiles, inv_n, e); break;
+    }
     FD_CHECK_LAUNCH("k_ln_finalize");
     return FD_OK;
 }
