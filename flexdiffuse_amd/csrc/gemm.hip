@@ -1548,13 +1548,45 @@ static int launch_epi(GemmArgs& g, int batch, hipStream_t st) {
 // (ldr > 0) a residual of row stride ldr: the row-complete 256x320 tile on the LDS-DMA path with the lean
 // epilogue and LDS-staged biases (FD_GEMM_FAST_EPI / FD_GEMM_BIAS_LDS / FD_GEMM_NO_DMA are A/B switches that
 // take those away).  Callers that get 0 run fd_ln_row_stats_f16 on the output instead.
+// fraction of the CU slots busy over the launch's rounds (slots = 256 CUs x workgroups per CU)
+static int g_t23 = getenv("FD_GEMM_T23") ? atoi(getenv("FD_GEMM_T23")) : 1;   // 0: never pick the 288x160 tile by rule (A/B)
+static double fd_round_eff(long long tiles, int slots) {
+    return (double)tiles / (double)((long long)slots * ((tiles + slots - 1) / slots));
+}
+
+// How fd_gemm_f16 honours ln_stats_out for an [M][N] output: 0 not at all, 1 finished pairs (the row-complete 256x320
+// tile), k > 1 slabs of per-n-tile partial sums from a 160-wide tile; *tile = the tile shape it will use.
+static int fd_stats_plan(int M, int N, int* tile) {
+    if (N < 320 || N % 160 != 0) return 0;
+    // rows = 9 x 2^k (768x768 images): the 288-row tile where it fills the rounds better than the 256-row shapes
+    const bool ok23 = g_t23 && M % 288 == 0 && M >= 1152;
+    if (N == 320 && M % 256 == 0) {
+        if (ok23 && fd_round_eff((long long)(M / 288) * 2, 256) > fd_round_eff(M / 256, 256) + 0.08) {
+            *tile = 23;
+            return 2;
+        }
+        *tile = 16;
+        return 1;
+    }
+    if (ok23 && (M % 128 != 0 ||
+                 fd_round_eff((long long)(M / 288) * (N / 160), 256) >
+                     (M % 256 == 0 && M > 4096 ? fd_round_eff((long long)(M / 256) * (N / 160), 256)
+                                                : fd_round_eff((long long)(M / 128) * (N / 160), 512)) + 0.08)) {
+        *tile = 23;
+        return N / 160;
+    }
+    if (N == 320 || M % 128 != 0) return 0;
+    *tile = (M % 256 == 0 && M > 4096) ? 13 : 12;
+    return N / 160;
+}
+
 extern "C" int fd_gemm_can_emit_row_stats(int M, int N, int K, int ldc, int ldr) {
     if (!(g_use_dma && g_fast_epi && g_bias_lds)) return 0;
     if (M <= 0 || K <= 0 || K % 8 != 0) return 0;
-    if (N == 320 ? M % 256 != 0 : (N <= 320 || N % 160 != 0 || M % 128 != 0)) return 0;
     if (ldc < N || (ldc & 7) != 0 || (ldr != 0 && (ldr < N || (ldr & 3) != 0))) return 0;
     if (2ull * ((unsigned long long)(M - 1) * (unsigned long long)ldc + N) >= 0x7fffffffull) return 0;
-    return N == 320 ? 1 : N / 160;   // n-tiles of partial sums the caller must provide and finalise (1: finalised in place)
+    int tile = 0;
+    return fd_stats_plan(M, N, &tile);   // slabs of partial sums the caller must provide and finalise (1: finalised in place)
 }
 
 extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
@@ -1747,21 +1779,42 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         best_tile = 20;
         best_split = 1;
     }
+    // Row counts of the form 9 x 2^k (768x768 images: 96x96 / 48x48 / 24x24 / 12x12 latents) leave the 256-row tiles
+    // with 288-, 72- or 18-tile columns -- 2.25 rounds on 256 CUs, the last one a quarter full.  288 x 160 (12 waves,
+    // 48x80 wave tiles, otherwise the 256x160 kernel) divides those rows exactly: 73728 x 320 -> 512 tiles = 2 rounds.
+    if (g_t23 && n160 && g.M % 288 == 0 && g.M >= 1152 && (best_tile == 13 || best_tile == 12 || best_tile == 20) && !g.phase) {
+        const auto eff = [](long long t) { return (double)t / (double)(256 * ((t + 255) / 256)); };
+        const int bm_cur = best_tile == 13 ? 256 : 128;
+        const long long t_cur = (long long)fd_cdiv(g.M, bm_cur) * (g.N / 160) * batch * best_split;
+        long long t23 = (long long)(g.M / 288) * (g.N / 160) * batch;
+        int split23 = 1;
+        if (best_split > 1 || (g.K + g.K2 > 1280 && batch == 1 && g.N % 4 == 0 && g.ws)) {
+            while (t23 * split23 < 224 && split23 < 16 && nk_all / (split23 * 2) >= 4 &&
+                   (size_t)(split23 * 2) * g.M * g.N * 4 <= (size_t)d->workspace_bytes)
+                split23 *= 2;
+        }
+        // (128-row tiles run two workgroups per CU: their rounds are 512 slots)
+        const double e_cur = bm_cur == 256 ? eff(t_cur) : (double)t_cur / (double)(512 * ((t_cur + 511) / 512));
+        if (eff(t23 * split23) > e_cur + 0.08) {
+            best_tile = 23;
+            best_split = split23;
+        }
+    }
     if (d->tile) best_tile = d->tile;
     if (d->split_k > 0) best_split = d->split_k;
     if (g.ln_stats) best_split = 1;   // the split-K finish kernel does not know the fold
     if (d->ln_stats_out) {
-        // N == 320: the 256x320 tile spans the whole row and finalises (rstd, -mean rstd) itself.  N a larger multiple of
-        // 160: the 160-wide tiles write raw per-n-tile partial sums [N / 160][M][2] for fd_ln_finalize_stats_f32.
-        const bool whole = g.N == 320 && g.M % 256 == 0;
-        const bool parts = g.N > 320 && g.N % 160 == 0 && g.M % 128 == 0;
-        FD_CHECK_ARG((whole || parts) && !d->conv && !d->trans_out && !d->out_f32 && batch == 1, FD_ESHAPE,
-                     "fd_gemm_f16: ln_stats_out needs N == 320 with M %% 256 == 0, or N %% 160 == 0 with M %% 128 == 0 (got M=%d N=%d)", g.M, g.N);
+        // N == 320: the 256x320 tile spans the whole row and finalises (rstd, -mean rstd) itself.  Wider rows (and N == 320
+        // at row counts the 288-row tile divides better): the 160-wide tiles write raw per-n-tile partial sums
+        // [N / 160][M][2] for fd_ln_finalize_stats_f32.  fd_gemm_can_emit_row_stats tells the caller which it will be.
+        int stile = 0;
+        const int slabs = fd_stats_plan(g.M, g.N, &stile);
+        FD_CHECK_ARG(slabs > 0 && !d->conv && !d->trans_out && !d->out_f32 && batch == 1, FD_ESHAPE,
+                     "fd_gemm_f16: ln_stats_out needs N == 320 with M %% 256 == 0, or N %% 160 == 0 with M %% 128 == 0 or M %% 288 == 0 (got M=%d N=%d)", g.M, g.N);
         g.ln_stats_out = d->ln_stats_out;
         g.ln_eps = d->ln_eps > 0.f ? d->ln_eps : 1e-5f;
-        if (whole) best_tile = 16;
-        else if (best_tile != 13 && best_tile != 12 && best_tile != 20) best_tile = (g.M % 256 == 0 && g.M > 4096) ? 13 : 12;
-        if (best_tile == 13 && g.M % 256 != 0) best_tile = 12;
+        // (a caller-forced 160-wide tile of the same row count keeps the slab layout)
+        if (!(slabs > 1 && stile != 23 && (best_tile == 12 || best_tile == 20 || (best_tile == 13 && g.M % 256 == 0)))) best_tile = stile;
         best_split = 1;
     }
     {
@@ -1792,6 +1845,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
             case 9: case 12: case 20: bm = 128; bn = 160; break;
             case 10: bm = 128; bn = 128; break;
             case 13: bm = 256; bn = 160; break;
+            case 23: bm = 288; bn = 160; break;
             case 14: bm = 256; bn = 128; break;
             case 15: bm = 256; bn = 256; break;
             case 16: bm = 256; bn = 320; break;
@@ -1805,11 +1859,11 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         FD_CHECK_ARG(!geglu && batch == 1 && g.N % 4 == 0 && g.ws &&
                          (size_t)best_split * g.M * g.N * 4 <= (size_t)d->workspace_bytes,
                      FD_ESHAPE, "fd_gemm_f16: split_k=%d not possible for this problem", best_split);
-    if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7 || best_tile == 9 || best_tile == 12 || best_tile == 13 || best_tile == 16 || best_tile == 20)) best_tile = 1;
+    if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7 || best_tile == 9 || best_tile == 12 || best_tile == 13 || best_tile == 16 || best_tile == 20 || best_tile == 23)) best_tile = 1;
     g.split_k = best_split;
     g.tap_fast = g.mode == MODE_CONV && (g_tap_fast == 2 || (g_tap_fast == 1 && best_tile == 16));
     fd_prof_begin(FD_FAMILY_GEMM, st, flops);
-    if (g.ln_stats && !(best_tile == 9 || best_tile == 10 || (best_tile >= 12 && best_tile <= 16) || best_tile == 20)) {
+    if (g.ln_stats && !(best_tile == 9 || best_tile == 10 || (best_tile >= 12 && best_tile <= 16) || best_tile == 20 || best_tile == 23)) {
         // small problems: the generic epilogue with the fold compiled in (64x64 for few rows)
         rc = best_tile == 4 ? launch_mode<64, 64, false, false, 2, 2, 2, 7>(g, batch, st)
                             : launch_mode<128, 128, false, false, 2, 2, 2, 7>(g, batch, st);
@@ -1828,6 +1882,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         case 11: rc = launch<128, 64, false, 4>(g, batch, st); break;
         case 12: rc = launch_epi<128, 160, 8, 2, 2, 38 + 256>(g, batch, st); break;   // 16 waves, 16x80 wave tiles
         case 13: rc = launch_epi<256, 160, 8, 2, 2, 38 + 256>(g, batch, st); break;   // 16 waves, 32x80 wave tiles
+        case 23: rc = launch_epi<288, 160, 6, 2, 2, 38 + 256>(g, batch, st); break;   // 12 waves, 48x80 wave tiles (rows = 9 x 2^k: 768^2 images)
         case 14: rc = launch_epi<256, 128, 8, 2, 2, 110>(g, batch, st); break;   // 16 waves, 32x64 wave tiles
         case 8: rc = launch<256, 128, false, 4, 3>(g, batch, st); break;
         case 15: rc = launch_epi<256, 256, 4, 2, 4, 110>(g, batch, st); break;  // 16 waves, 64x64 wave tiles

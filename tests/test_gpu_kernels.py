@@ -299,7 +299,7 @@ def test_cfg_ddim_and_layout(dev):
 
 @pytest.mark.parametrize('tile,split', [(1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (1, 2), (2, 4),
                                         (5, 2), (6, 4), (3, 8), (7, 1), (8, 1), (7, 2), (9, 1), (10, 2), (12, 1), (13, 1), (13, 4),
-                                        (14, 1), (15, 1), (15, 2), (16, 1), (16, 2)])
+                                        (14, 1), (15, 1), (15, 2), (16, 1), (16, 2), (20, 1), (23, 1), (23, 2)])
 def test_gemm_every_tile_and_split(dev, tile, split):
     """Each block tile (incl. the 8-wave 256-row ones) and split-K factor gives the same
     result as torch on a conv and on a ragged linear problem."""
@@ -591,12 +591,14 @@ def test_upsample_conv_phase_decomposition(dev, B, H, Cin, Cout):
 
 
 @pytest.mark.parametrize('M,N,K,res', [(16384, 640, 640, True), (4096, 1280, 1280, True), (4096, 1280, 1280, False),
-                                       (1024, 1280, 1280, True), (16384, 640, 640, False), (128, 480, 320, True)])
+                                       (1024, 1280, 1280, True), (16384, 640, 640, False), (128, 480, 320, True),
+                                       (36864, 320, 320, True), (2304, 640, 640, True), (18432, 640, 640, False)])
 def test_gemm_emits_partial_row_stats_for_wide_rows(dev, M, N, K, res):
     '''fd_gemm_desc.ln_stats_out with N > 320: the 160-wide tiles write raw (sum, sum of squares) per n-tile,
     fd_ln_finalize_stats_f32 combines them -> the same (rstd, -mean rstd) as fd_ln_row_stats_f16 on the stored rows
     (one-pass E[x^2] - mean^2 in fp32 vs exact two-pass: 2e-4), and the output itself equals the launch without
-    statistics up to tile-choice rounding.  Shapes: the UNet's 32x32 / 16x16 / 8x8-level producers (tiles 13, 20, 12).'''
+    statistics up to tile-choice rounding.  Shapes: the UNet's 32x32 / 16x16 / 8x8-level producers (tiles 13, 20, 12) and the
+    9 x 2^k row counts of 768x768 images, which take the 288-row tile (N = 320 then emits two slabs instead of finished pairs).'''
     from flexdiffuse_amd import ops
     g = torch.Generator().manual_seed(M + N)
     a = torch.randn((M, K), generator=g).half().to(dev)

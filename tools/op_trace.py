@@ -5,11 +5,15 @@ import torch
 from flexdiffuse_amd import build, hip, ops
 from flexdiffuse_amd.unet import UNet2DConditionModel
 dev = torch.device('cuda:0')
-sds = build.synthetic_state_dicts('sd15', seed=0, parts=('unet',))
-unet = UNet2DConditionModel(sds['unet'], build.configs('sd15')[0], dev)
-B = 8
-x = torch.randn((B, 4, 64, 64), device=dev)
-ctx = torch.randn((2 * B, 77, 768), device=dev).half()
+# python tools/op_trace.py [preset = sd15] [latent size = 64] [batch = 8]   (c4: sd15 96 4; c5: sd21 96 8)
+PRESET = sys.argv[1] if len(sys.argv) > 1 else 'sd15'
+LAT = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+sds = build.synthetic_state_dicts(PRESET, seed=0, parts=('unet',))
+ucfg = build.configs(PRESET)[0]
+unet = UNet2DConditionModel(sds['unet'], ucfg, dev)
+x = torch.randn((B, 4, LAT, LAT), device=dev)
+ctx = torch.randn((2 * B, 77, ucfg.cross_attention_dim), device=dev).half()
 for i in range(3):
     unet.forward_nhwc(x, 400 - i, ctx, rep=2)
 torch.cuda.synchronize()
