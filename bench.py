@@ -316,8 +316,8 @@ def plumbing_rank(args) -> None:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=8, help='images per GPU')
     ap.add_argument('--ddim-steps', type=int, default=50)
     ap.add_argument('--size', type=int, default=512)
@@ -419,6 +419,13 @@ def main():
 
     for w in range(args.warmup):
         one_pass()
+    # The heap now holds the models, the tokenizer tables and the recorded launch plans (millions of long-lived
+    # objects): a full collection over it is a 50-100 ms host stall, and the collector would schedule one whenever a
+    # pass's temporaries push the young generations over their thresholds.  Collect once, then move everything that
+    # survived into the permanent generation -- later collections only look at what a pass itself allocates.
+    import gc
+    gc.collect()
+    gc.freeze()
     sync()
     t0 = time.time()
     for k in range(args.steps):
