@@ -14,7 +14,9 @@ of GPUs; no CUDA autocast context is needed (the kernels are fp16 MFMA by constr
 '''
 from __future__ import annotations
 
+import gc
 import math
+import os
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -68,6 +70,11 @@ class Runner():
         self.guide = Guide(clip, tok, device=device)
         self.generator = torch.Generator(device='cpu')     # E6: host generator
         self.eta = 0.0                                      # E5: never overwritten
+        # the models and tokenizer tables are millions of long-lived objects: a full collection over them is a 50-100 ms
+        # host stall between denoising loops (measured in bench.py's timed region); park them in the permanent generation
+        if os.environ.get('FD_GC_FREEZE', '1') != '0':
+            gc.collect()
+            gc.freeze()
 
     def _set_seed(self, seed: Optional[int]):
         '''Falsy seed -> a random one; otherwise clamped to [0, 2^31 - 1] (utils.py:78-83).'''
