@@ -1782,7 +1782,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     // Row counts of the form 9 x 2^k (768x768 images: 96x96 / 48x48 / 24x24 / 12x12 latents) leave the 256-row tiles
     // with 288-, 72- or 18-tile columns -- 2.25 rounds on 256 CUs, the last one a quarter full.  288 x 160 (12 waves,
     // 48x80 wave tiles, otherwise the 256x160 kernel) divides those rows exactly: 73728 x 320 -> 512 tiles = 2 rounds.
-    if (g_t23 && n160 && g.M % 288 == 0 && g.M >= 1152 && (best_tile == 13 || best_tile == 12 || best_tile == 20) && !g.phase) {
+    if (g_t23 && n160 && g.M % 288 == 0 && g.M >= 1152 && (best_tile == 13 || best_tile == 12 || best_tile == 20)) {
         const auto eff = [](long long t) { return (double)t / (double)(256 * ((t + 255) / 256)); };
         const int bm_cur = best_tile == 13 ? 256 : 128;
         const long long t_cur = (long long)fd_cdiv(g.M, bm_cur) * (g.N / 160) * batch * best_split;
