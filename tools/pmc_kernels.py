@@ -37,6 +37,21 @@ if only == 'r03':
     x3 = ops.Act((torch.randn((16*8*8,1280), generator=g)*0.7).half().to(dev), 16,8,8)
     w3 = ops.prep_conv(torch.randn((1280,1280,3,3), generator=g)*(9*1280)**-0.5, torch.randn(1280, generator=g), dev)
     for _ in range(3): ops.conv2d(x3, w3)
+    # late round 3: the 288x160 tile on a 768x768 level-0 conv (c4: CFG batch 8 x 96x96 = 73728 rows), the head-dim-80 fused
+    # cross-attention (32x32 level), a 640-wide producer that emits per-n-tile partial LayerNorm sums
+    x4 = ops.Act((torch.randn((8*96*96,320), generator=g)*0.7).half().to(dev), 8,96,96)
+    for _ in range(3): ops.conv2d(x4, w)
+    a1 = torch.randn((16384,640), generator=g).half().to(dev)
+    r1 = torch.randn((16384,640), generator=g).half().to(dev)
+    l1 = ops.prep_linear(torch.randn((640,640), generator=g)*640**-0.5, torch.randn(640, generator=g), dev)
+    parts = torch.empty((ops.can_emit_row_stats(16384, 640, 640), 16384, 2), dtype=torch.float32, device=dev)
+    for _ in range(3): ops.gemm(a1, l1, residual=r1, ln_stats_out=parts)
+    st1 = ops.ln_finalize_stats(parts, 640)
+    lq1 = ops.prep_linear_ln(torch.randn((640,640), generator=g)*640**-0.5*0.23, None, torch.ones(640), torch.zeros(640), dev)
+    kd1 = torch.randn((16*L,640), generator=g).half().to(dev)
+    vt1 = torch.zeros((16,640,80), dtype=torch.float16); vt1[:,:,:L] = torch.randn((16,640,L), generator=g).half()
+    img1 = ops.xattn_pack_kv(kd1, vt1.to(dev), 16, L, 8, 80)
+    for _ in range(3): ops.xattn_q(a1, lq1, st1, img1, 1024, L, 8, 80)
     torch.cuda.synchronize(); sys.exit(0)
 if only == 'attn':
     for (B,N,heads,d) in [(16,4096,8,40),(16,1024,8,80)]:
