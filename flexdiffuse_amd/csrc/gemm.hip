@@ -64,6 +64,8 @@ struct GemmArgs {
     const half_t* A2;   // conv + appended 1x1 phase: after the conv's K-tiles the loop runs K2 more columns over the rows of
     unsigned a2_bytes;
     int lda2, K2;       // A2 [M][lda2] (the ResBlock's shortcut conv folded into conv2's accumulation); W is [N][K + K2]
+    long long strideBias;   // batch > 1: floats between the biases of consecutive batches (fd_gemm_desc.batch_stride_bias)
+    int stats_rows;         // ln_stats_out: rows of the whole launch (batch x M): slab stride of the partial sums
     int sk_flat;   // split-K on a flat 1-D grid: slice = blockIdx.x % split_k, tile = blockIdx.x / split_k (see k_gemm_f16_dma)
     float* ws;     // [split_k][M][N] fp32
 };
@@ -339,12 +341,12 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
                     if constexpr (WN_ == 2) {   // the 160-wide tiles (the 256x320 tile, WN_ == 4, spans its row)
                         // the row spans several n-tiles: this tile's raw (sum, sum of squares) goes to slab `tile_n` of
                         // ln_stats_out [N / BN][M][2]; fd_ln_finalize_stats_f32 combines the slabs in a fixed order
-                        *reinterpret_cast<floatx2*>(g.ln_stats_out + 2 * ((size_t)(col0 / (NI * 16 * WN_)) * g.M + m0 + tr)) = floatx2{s1, s2};
+                        *reinterpret_cast<floatx2*>(g.ln_stats_out + 2 * ((size_t)(col0 / (NI * 16 * WN_)) * g.stats_rows + (size_t)z * g.M + m0 + tr)) = floatx2{s1, s2};
                     } else {
                         const float mean = s1 * inv_n;
                         const float var = fmaxf(fmaf(-mean, mean, s2 * inv_n), 0.f);
                         const float rstd = rsqrtf(var + g.ln_eps);
-                        *reinterpret_cast<floatx2*>(g.ln_stats_out + 2 * (size_t)(m0 + tr)) = floatx2{rstd, -mean * rstd};
+                        *reinterpret_cast<floatx2*>(g.ln_stats_out + 2 * ((size_t)z * g.M + m0 + tr)) = floatx2{rstd, -mean * rstd};
                     }
                 }
             }
@@ -879,7 +881,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     // epilogue reads them without a branch.
     if ((g.bias && g.bias_lds) || (EPI != 0 && EPI != 7)) {
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(g.bias ? (const void*)g.bias : (const void*)g.W), 0, g.bias ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
+            (void*)(g.bias ? (const void*)(g.bias + (size_t)z * g.strideBias) : (const void*)g.W), 0, g.bias ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
         if (wave * 64 + lane < BN)   // lanes past the tile would spill into the next LDS buffer
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(bias_s + wave * 64), 4,
                                                      (unsigned)(n0 + wave * 64 + lane) * 4u, 0, 0, 0);
@@ -1471,7 +1473,7 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         const int occ = (BM >= 256 || lds > 80 * 1024) ? 1 : (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);  // workgroups / CU
         const int slots = 256 * occ;
         const int nkt = (g.K + BK - 1) / BK / g.split_k;
-        const bool persistent = NS == 2 && BN != 320 && g.K2 == 0 && !g.phase && !g.ln_stats_out && (g_persist_mode == 2 ||
+        const bool persistent = NS == 2 && BN != 320 && g.K2 == 0 && !g.phase && !g.ln_stats_out && g.strideBias == 0 && (g_persist_mode == 2 ||
                                 (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots));
         if constexpr (EPI >= 1 && EPI <= 3) {
             // the persistent loop does not stage the per-sample bias: generic epilogue there
@@ -1589,7 +1591,7 @@ static double fd_round_eff(long long tiles, int slots) {
 
 // How fd_gemm_f16 honours ln_stats_out for an [M][N] output: 0 not at all, 1 finished pairs (the row-complete 256x320
 // tile), k > 1 slabs of per-n-tile partial sums from a 160-wide tile; *tile = the tile shape it will use.
-static int fd_stats_plan(int M, int N, int* tile) {
+static int fd_stats_plan(int M, int N, int* tile, int batch = 1) {
     if (N < 320 || N % 160 != 0) return 0;
     // rows = 9 x 2^k (768x768 images): the 288-row tile where it fills the rounds better than the 256-row shapes
     const bool ok23 = g_t23 && M % 288 == 0 && M >= 1152;
@@ -1609,7 +1611,7 @@ static int fd_stats_plan(int M, int N, int* tile) {
         return N / 160;
     }
     if (N == 320 || M % 128 != 0) return 0;
-    *tile = (M % 256 == 0 && M > 4096) ? 13 : 12;
+    *tile = (M % 256 == 0 && (long long)M * batch > 4096) ? 13 : 12;   // (the slab count does not depend on the tile)
     return N / 160;
 }
 
@@ -1646,6 +1648,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     g.ldb2 = d->ld_bias2 > 0 ? d->ld_bias2 : d->N;
     g.strideA = d->batch_stride_a; g.strideW = d->batch_stride_w;
     g.strideC = d->batch_stride_c; g.strideRes = d->batch_stride_res;
+    g.strideBias = d->batch_stride_bias;
     g.rows_per_batch = d->rows_per_sample > 0 ? d->rows_per_sample : d->M;
     g.act = d->act; g.out_f32 = d->out_f32; g.trans_out = d->trans_out;
     g.strideT = d->trans_sample_stride; g.ldt = d->trans_ld;
@@ -1841,10 +1844,13 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         // at row counts the 288-row tile divides better): the 160-wide tiles write raw per-n-tile partial sums
         // [N / 160][M][2] for fd_ln_finalize_stats_f32.  fd_gemm_can_emit_row_stats tells the caller which it will be.
         int stile = 0;
-        const int slabs = fd_stats_plan(g.M, g.N, &stile);
-        FD_CHECK_ARG(slabs > 0 && !d->conv && !d->trans_out && !d->out_f32 && batch == 1, FD_ESHAPE,
+        const int slabs = fd_stats_plan(g.M, g.N, &stile, batch);
+        // (batch > 1: the batches' rows must follow each other in C so that row index = batch * M + m)
+        FD_CHECK_ARG(slabs > 0 && !d->conv && !d->trans_out && !d->out_f32 &&
+                         (batch == 1 || d->batch_stride_c == (int64_t)g.M * g.ldc), FD_ESHAPE,
                      "fd_gemm_f16: ln_stats_out needs N == 320 with M %% 256 == 0, or N %% 160 == 0 with M %% 128 == 0 or M %% 288 == 0 (got M=%d N=%d)", g.M, g.N);
         g.ln_stats_out = d->ln_stats_out;
+        g.stats_rows = g.M * batch;
         g.ln_eps = d->ln_eps > 0.f ? d->ln_eps : 1e-5f;
         // (a caller-forced 160-wide tile of the same row count keeps the slab layout)
         if (!(slabs > 1 && stile != 23 && (best_tile == 12 || best_tile == 20 || (best_tile == 13 && g.M % 256 == 0)))) best_tile = stile;
@@ -1862,6 +1868,11 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         FD_CHECK_ARG(a_elems < 0x7fffffffull && w_elems < 0x7fffffffull && c_elems < 0x7fffffffull, FD_ESHAPE,
                      "fd_gemm_f16: operand of %llu elements exceeds the 2^31-element addressing limit; "
                      "split the batch", a_elems > w_elems ? a_elems : w_elems);
+        // a per-batch bias is only staged by the LDS-DMA kernels (the global-memory fallbacks of the epilogues read bias[n])
+        FD_CHECK_ARG(g.strideBias == 0 || (batch > 1 && g.bias && g_use_dma && g.bias_lds && 2 * a_elems < 0x7fffffffull &&
+                                          2 * w_elems < 0x7fffffffull && d->split_k <= 1),
+                     FD_ESHAPE, "fd_gemm_f16: batch_stride_bias needs batch > 1, a bias, the LDS-DMA path with LDS-staged biases and no split-K");
+        if (g.strideBias) best_split = 1;
         if (2 * a_elems >= 0x7fffffffull || 2 * w_elems >= 0x7fffffffull) {
             // the register-staged kernel knows neither the LayerNorm fold nor the producer statistics: refuse
             // rather than hand the consumer GEMM uninitialised statistics

@@ -378,6 +378,97 @@ static bool gn_try_slab(const void* x, void* y, const float* gamma, const float*
     return false;
 }
 
+// ---------------------------------------------------------------------------------------
+// GroupNorm folded into the linear layer that consumes it (fd_groupnorm_fold_linear_f16): after the statistics pass the
+// per-sample weights w_out[b][n][c] = wg[n][c] * rstd[b][g(c)] and biases
+// bias_out[b][n] = biasf[n] - sum_g mean[b][g] rstd[b][g] S[n][g] are all the "apply" there is -- the consumer GEMM reads
+// the un-normalised activation with sample b's weights.  grid (N / ROWS, B); 16-byte chunks of the weight rows.
+// ---------------------------------------------------------------------------------------
+#define GNF_ROWS 16
+__global__ __launch_bounds__(256) void k_gn_fold_linear(const float* __restrict__ part, int nchunk_stats, int HW, int C, int G, float eps,
+                                                        const half_t* __restrict__ wg, const float* __restrict__ S,
+                                                        const float* __restrict__ biasf, int N, half_t* __restrict__ w_out,
+                                                        float* __restrict__ bias_out) {
+    __shared__ float rstd_s[64], mr_s[64];   // G <= 64
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (tid < G) {   // the combine of k_gn_apply: partial sums in a fixed order, fp64
+        double s = 0.0, q = 0.0;
+        const float2* src = reinterpret_cast<const float2*>(part) + ((size_t)b * nchunk_stats) * G + tid;
+        for (int k = 0; k < nchunk_stats; ++k) {
+            const float2 v = src[(size_t)k * G];
+            s += (double)v.x;
+            q += (double)v.y;
+        }
+        const double n = (double)HW * (C / G);
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        rstd_s[tid] = (float)rstd;
+        mr_s[tid] = (float)(mean * rstd);
+    }
+    __syncthreads();
+    const int n0 = blockIdx.x * GNF_ROWS, rows = min(GNF_ROWS, N - n0);
+    const int c8 = C >> 3, cpg = C / G;
+    for (int i = tid; i < rows * c8; i += 256) {
+        const int r = i / c8, cc = i - r * c8;
+        const half8 v = *reinterpret_cast<const half8*>(wg + (size_t)(n0 + r) * C + cc * 8);
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (half_t)((float)v[k] * rstd_s[(cc * 8 + k) / cpg]);
+        *reinterpret_cast<half8*>(w_out + ((size_t)b * N + n0 + r) * C + cc * 8) = o;
+    }
+    if (tid < rows) {
+        const float* Sn = S + (size_t)(n0 + tid) * G;
+        float acc = biasf[n0 + tid];
+        for (int g = 0; g < G; ++g) acc = fmaf(-mr_s[g], Sn[g], acc);
+        bias_out[(size_t)b * N + n0 + tid] = acc;
+    }
+}
+
+// launch shape of the streaming statistics pass (shared by fd_groupnorm_nhwc_ld_f16's two-pass form and the fold)
+static void gn_stats_shape(int B, int HW, int C, int* PL, int* threads, int* nchunk, int* ppc) {
+    const int c8 = C / 8;
+    int pl = 512 / c8;
+    if (pl < 1) pl = 1;
+    if (pl > HW) pl = HW;
+    int nc = 256 / B;
+    if (nc < 1) nc = 1;
+    if (nc > GN_MAX_CHUNKS) nc = GN_MAX_CHUNKS;
+    int pp = fd_cdiv(HW, nc);
+    if (pp < pl) pp = pl;
+    *PL = pl;
+    *threads = ((c8 * pl + 63) / 64) * 64;
+    *ppc = pp;
+    *nchunk = fd_cdiv(HW, pp);
+}
+
+extern "C" int fd_groupnorm_fold_linear_f16(const void* x, int ldx, float* ws, int B, int HW, int C, int G, float eps,
+                                            const void* wg, const float* S, const float* biasf, int N,
+                                            void* w_out, float* bias_out, void* stream) {
+    FD_PLAN(fd_groupnorm_fold_linear_f16(x, ldx, ws, B, HW, C, G, eps, wg, S, biasf, N, w_out, bias_out, fd_s_));
+    FD_CHECK_ARG(x && ws && wg && S && biasf && w_out && bias_out, FD_EINVAL, "fd_groupnorm_fold_linear_f16: null pointer");
+    FD_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && N > 0, FD_EINVAL, "fd_groupnorm_fold_linear_f16: bad dims");
+    FD_CHECK_ARG(C % 8 == 0 && C % G == 0 && G <= 64 && C / 8 <= 1024, FD_ESHAPE,
+                 "fd_groupnorm_fold_linear_f16: C=%d must be a multiple of 8 and of G=%d (G <= 64)", C, G);
+    FD_CHECK_ARG(ldx >= C && ldx % 8 == 0 && ((uintptr_t)x | (uintptr_t)wg | (uintptr_t)w_out) % 16 == 0, FD_ESHAPE,
+                 "fd_groupnorm_fold_linear_f16: ldx=%d must be >= C=%d, a multiple of 8; x / wg / w_out 16-byte aligned", ldx, C);
+    FD_CHECK_ARG((long long)B * HW * ldx < 0x7fffffffLL, FD_ESHAPE, "fd_groupnorm_fold_linear_f16: tensor too large");
+    hipStream_t st = (hipStream_t)stream;
+    int PL, threads, nchunk, ppc;
+    gn_stats_shape(B, HW, C, &PL, &threads, &nchunk, &ppc);
+    const size_t lds1 = (size_t)PL * C * 2 * sizeof(float);
+    FD_CHECK_ARG(lds1 <= 64 * 1024, FD_ESHAPE, "fd_groupnorm_fold_linear_f16: stats LDS too large");
+    // priced as the statistics read only (2 B/element): the apply pass it replaces is gone
+    fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 2.0);
+    hipLaunchKernelGGL(k_gn_stats, dim3(nchunk, B), dim3(threads), lds1, st, (const half_t*)x, ws, HW, C, G, PL, ppc, ldx);
+    hipLaunchKernelGGL(k_gn_fold_linear, dim3(fd_cdiv(N, GNF_ROWS), B), dim3(256), 0, st, (const float*)ws, nchunk, HW, C, G, eps,
+                       (const half_t*)wg, S, biasf, N, (half_t*)w_out, bias_out);
+    fd_prof_end(FD_FAMILY_GROUPNORM, st);
+    FD_CHECK_LAUNCH("k_gn_stats/k_gn_fold_linear");
+    return FD_OK;
+}
+
 extern "C" int64_t fd_groupnorm_workspace_floats(int B, int G) {
     return (int64_t)B * GN_MAX_CHUNKS * G * 2;
 }

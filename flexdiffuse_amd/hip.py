@@ -55,6 +55,7 @@ _SIGNATURES = {
     'fd_layernorm_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'fd_ln_row_stats_f16': (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
     'fd_ln_finalize_stats_f32': (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
+    'fd_groupnorm_fold_linear_f16': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_float, P, P, P, c_int, P, P, P]),
     'fd_softmax_rows_f16': (c_int, [P, c_int, c_int, c_int, c_float, P]),
     'fd_nchw_f32_to_nhwc_f16': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'fd_nhwc_f32_to_nchw_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P]),
@@ -78,7 +79,7 @@ _SIGNATURES = {
     'fd_cast_f16_to_f32': (c_int, [P, P, c_int64, P]),
 }
 
-ABI_VERSION = 7   # FD_ABI_VERSION in include/flexdiffuse_hip.h
+ABI_VERSION = 8   # FD_ABI_VERSION in include/flexdiffuse_hip.h
 _lib: Optional[ctypes.CDLL] = None
 
 

@@ -32,7 +32,8 @@ class fd_gemm_desc(ctypes.Structure):
                 ('batch_stride_c', c_int64), ('batch_stride_res', c_int64),
                 ('tile', c_int32), ('split_k', c_int32), ('workspace', c_void_p),
                 ('workspace_bytes', c_int64), ('ln_stats', c_void_p), ('ln_colsum', c_void_p),
-                ('ln_stats_out', c_void_p), ('ln_eps', c_float), ('A2', c_void_p), ('lda2', c_int32), ('K2', c_int32)]
+                ('ln_stats_out', c_void_p), ('ln_eps', c_float), ('A2', c_void_p), ('lda2', c_int32), ('K2', c_int32),
+                ('batch_stride_bias', c_int64)]
 
 
 class fd_attention_desc(ctypes.Structure):
@@ -519,6 +520,69 @@ def groupnorm(x: Act, gamma: torch.Tensor, beta: torch.Tensor, G: int, eps: floa
     hip.call('fd_groupnorm_nhwc_ld_f16', x.t.data_ptr(), x.t.stride(0), out.data_ptr(), gamma.data_ptr(),
              beta.data_ptr(), ws.data_ptr(), x.B, x.HW, x.C, G, eps, int(silu), hip.stream())
     return Act(out, x.B, x.H, x.W)
+
+
+@dataclass
+class GNFold:
+    '''Model constants of a GroupNorm folded into the linear layer behind it (prep_gn_fold).'''
+    wg: torch.Tensor      # fp16 [N][C] = W diag(gamma)
+    S: torch.Tensor       # fp32 [N][G]: group sums of the ROUNDED wg (so the mean cancels exactly)
+    biasf: torch.Tensor   # fp32 [N] = bias + W beta
+    G: int
+    eps: float
+    N: int
+    C: int
+
+
+def prep_gn_fold(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, G: int, eps: float,
+                 dev) -> GNFold:
+    '''proj_in(GroupNorm(x)) as a per-sample linear layer on x itself (fd_groupnorm_fold_linear_f16).'''
+    w = w.reshape(w.shape[0], -1).float()
+    N, C = w.shape
+    wg = (w * gamma.float()[None, :]).half()
+    S = wg.float().reshape(N, G, C // G).sum(-1)
+    biasf = (b.float() if b is not None else torch.zeros(N)) + w @ beta.float()
+    return GNFold(wg.contiguous().to(dev), S.contiguous().to(dev), biasf.contiguous().to(dev), G, eps, N, C)
+
+
+def gn_fold_supported(B: int, HW: int, N: int) -> bool:
+    '''The fold pays where the per-sample weights (B x N x C) are smaller than the activation (B x HW x C) they stand
+    in for, and the consumer GEMM needs whole row tiles per sample.'''
+    mode = os.environ.get('FD_UNET_GN_FOLD', '1')    # 0: never; 1: where the map is >= 8x wider than the layer; 2: wherever N < HW
+    return mode != '0' and HW % 256 == 0 and B > 1 and (N * 8 <= HW if mode == '1' else N < HW)
+
+
+def gn_fold_linear(x: Act, gf: GNFold) -> Tuple[torch.Tensor, torch.Tensor]:
+    '''One statistics pass over x, then sample b's scaled weights [B][N][C] fp16 and bias [B][N] fp32.'''
+    assert x.t.stride(1) == 1 and x.C == gf.C
+    wb = _empty((x.B, gf.N, gf.C), torch.float16, x.t)
+    bb = _empty((x.B, gf.N), torch.float32, x.t)
+    ws = _gn_workspace(x.B, gf.G, x.t.device)
+    hip.call('fd_groupnorm_fold_linear_f16', x.t.data_ptr(), x.t.stride(0), ws.data_ptr(), x.B, x.HW, gf.C, gf.G, gf.eps,
+             gf.wg.data_ptr(), gf.S.data_ptr(), gf.biasf.data_ptr(), gf.N, wb.data_ptr(), bb.data_ptr(), hip.stream())
+    return wb, bb
+
+
+def gemm_per_sample(a: torch.Tensor, wb: torch.Tensor, bb: torch.Tensor, B: int, HW: int,
+                    ln_stats_out: Optional[torch.Tensor] = None, ln_eps: float = 1e-5) -> torch.Tensor:
+    '''a [B*HW][K] (row stride lda) @ wb[b][N][K]^T + bb[b] for the HW rows of sample b -> [B*HW][N] fp16: ONE launch
+    with batch = B, per-batch weights and bias (fd_gemm_desc.batch_stride_w / batch_stride_bias).'''
+    M, K = a.shape
+    _, N, Kw = wb.shape
+    assert M == B * HW and K == Kw and a.stride(1) == 1 and wb.is_contiguous() and bb.is_contiguous()
+    out = _empty((M, N), torch.float16, a)
+    d = fd_gemm_desc()
+    d.A, d.W, d.C, d.bias = a.data_ptr(), wb.data_ptr(), out.data_ptr(), bb.data_ptr()
+    d.M, d.N, d.K = HW, N, K
+    d.lda, d.ldw, d.ldc = a.stride(0), K, N
+    d.alpha, d.batch = 1.0, B
+    d.batch_stride_a, d.batch_stride_w, d.batch_stride_c, d.batch_stride_bias = HW * a.stride(0), N * K, HW * N, N
+    if ln_stats_out is not None:
+        assert ln_stats_out.shape[-2:] == (M, 2) and ln_stats_out.dtype == torch.float32 and ln_stats_out.is_contiguous()
+        d.ln_stats_out, d.ln_eps = ln_stats_out.data_ptr(), ln_eps
+    _sched(d, a.device)
+    hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+    return out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,

@@ -48,12 +48,15 @@ class _Res:
 
 
 class _Attn:
-    def __init__(self, sd, name, dev, heads, linear_proj):
+    def __init__(self, sd, name, dev, heads, linear_proj, groups=32):
         g = lambda k: sd[name + k]
         self.heads = heads
         self.ng, self.nb = ops.f32(g('.norm.weight'), dev), ops.f32(g('.norm.bias'), dev)
         w = g('.proj_in.weight')
         self.proj_in = ops.prep_linear(w.reshape(w.shape[0], w.shape[1]), g('.proj_in.bias'), dev)
+        # GroupNorm fold: norm -> proj_in as ONE per-sample linear layer on the un-normalised input (one statistics pass,
+        # no normalised activation written and re-read; ops.gn_fold_supported picks the levels where it pays)
+        self.gnf = ops.prep_gn_fold(w, g('.proj_in.bias'), g('.norm.weight'), g('.norm.bias'), groups, 1e-6, dev)
         w = g('.proj_out.weight')
         self.proj_out = ops.prep_linear(w.reshape(w.shape[0], w.shape[1]), g('.proj_out.bias'), dev)
         tb = '.transformer_blocks.0'
@@ -144,7 +147,7 @@ class UNet2DConditionModel():
             self._toff += r.cout
             return r
 
-        attn = lambda name, c: _Attn(sd, name, dev, heads[c], cfg.use_linear_projection)
+        attn = lambda name, c: _Attn(sd, name, dev, heads[c], cfg.use_linear_projection, cfg.norm_num_groups)
         self.down: List[dict] = []
         for i, c in enumerate(ch):
             blk = {'res': [], 'attn': [], 'down': None}
@@ -275,17 +278,19 @@ class UNet2DConditionModel():
         samples.'''
         B, HW, C = x.B, x.HW, a.C
         d = C // a.heads
-        h = ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False)
+        gn_fold = ops.gn_fold_supported(B, HW, C)
+        h = None if gn_fold else ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False)
         # LayerNorm fold: the GEMM that PRODUCES a LayerNorm input also writes its row statistics where one
         # tile spans the row (C == 320: the 64x64 level); elsewhere one read-only statistics pass
         # (C == 320: finished pairs; wider rows: raw partial sums per 160-column tile + a tiny finalise launch)
         emit = (a.ln_fold and a.ln_emit) and ops.can_emit_row_stats(B * HW, C, C)
 
-        def mkst(rows):
+        def mkst(rows, batch=1):
+            '''statistics buffer of a producer GEMM of `batch` x `rows` output rows (None: separate statistics pass)'''
             k = emit and ops.can_emit_row_stats(rows, C, C)
             if not k:
                 return None
-            return torch.empty((rows, 2) if k == 1 else (k, rows, 2), dtype=torch.float32, device=x.t.device)
+            return torch.empty((rows * batch, 2) if k == 1 else (k, rows * batch, 2), dtype=torch.float32, device=x.t.device)
 
         def fin(st, hh):
             '''(rstd, -mean rstd) of the rows of hh: emitted by its producer, finalised from its partial sums, or
@@ -293,8 +298,13 @@ class UNet2DConditionModel():
             if st is None:
                 return ops.ln_row_stats(hh)
             return st if st.dim() == 2 else ops.ln_finalize_stats(st, C)
-        st = mkst(B * HW)
-        h = ops.gemm(h.t, a.proj_in, ln_stats_out=st)
+        if gn_fold:
+            wb, bb = ops.gn_fold_linear(x, a.gnf)
+            st = mkst(HW, B)
+            h = ops.gemm_per_sample(x.t, wb, bb, B, HW, ln_stats_out=st)
+        else:
+            st = mkst(B * HW)
+            h = ops.gemm(h.t, a.proj_in, ln_stats_out=st)
         if a.ln_fold:
             st = fin(st, h)
             qk = ops.gemm(h, a.qk1, ln_stats=st)

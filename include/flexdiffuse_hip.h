@@ -32,7 +32,7 @@ extern "C" {
 #define FD_ESHAPE (-2) /* unsupported shape / alignment */
 #define FD_EHIP (-3)   /* HIP runtime error */
 
-#define FD_ABI_VERSION 7
+#define FD_ABI_VERSION 8
 
 int fd_abi_version(void);
 const char* fd_last_error(void);
@@ -206,6 +206,11 @@ typedef struct fd_gemm_desc {
      * with A = f, A2 = h instead of two.  W is [N][ldw] with ldw >= K + K2; K % 64 == 0, K2 % 64 == 0; LDS-DMA path only. */
     const void* A2;
     int32_t lda2, K2;
+    /* (ABI 8) batch > 1: `bias` advances by this many floats per batch (0: one bias for every batch).  With per-batch
+     * weights (batch_stride_w) this is the GroupNorm fold of fd_groupnorm_fold_linear_f16: sample b's rows are
+     * multiplied by ITS weights and get ITS bias.  LDS-DMA path with LDS-staged biases only.  With batch > 1,
+     * ln_stats_out needs batch_stride_c == M * ldc (row index = batch * M + m). */
+    int64_t batch_stride_bias;
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);
@@ -279,6 +284,16 @@ int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma, const floa
 int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const float* gamma, const float* beta,
                              float* ws, int B, int HW, int C, int G, float eps, int silu,
                              void* stream);
+/* GroupNorm folded into the linear layer that consumes it (the transformer block's norm -> proj_in, diffusers
+ * Transformer2DModel.norm / proj_in inside the `unet(...)` call of reference pipeline/guide.py:56-58):
+ *   proj_in(GN(x))[m][n] = sum_c (W[n][c] gamma_c rstd_{b,g(c)}) x[m][c] + (bias[n] + (W beta)[n] - sum_g mean_{b,g} rstd_{b,g} S[n][g])
+ * One statistics pass over x [B][HW][ldx] (the first launch of fd_groupnorm_nhwc_ld_f16), then per sample b the scaled
+ * weights w_out [B][N][C] fp16 and bias_out [B][N] fp32 from the model constants wg = W diag(gamma) (fp16 [N][C]),
+ * S[n][g] = sum_{c in g} wg[n][c] (fp32 [N][G]) and biasf = bias + W beta (fp32 [N]).  The normalised activation is never
+ * written: the consumer is fd_gemm_f16 with batch = B, batch_stride_w = N * C, batch_stride_bias = N on x itself. */
+int fd_groupnorm_fold_linear_f16(const void* x, int ldx, float* ws, int B, int HW, int C, int G, float eps,
+                                 const void* wg, const float* S, const float* biasf, int N,
+                                 void* w_out, float* bias_out, void* stream);
 /* LayerNorm over the last dim of fp16 x [rows][ldx] -> fp16 (or fp32) y [rows][ldy]. */
 int fd_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int rows,
                      int C, int ldx, int ldy, float eps, int out_f32, void* stream);

@@ -618,3 +618,54 @@ def test_gemm_emits_partial_row_stats_for_wide_rows(dev, M, N, K, res):
     # the slabs really are per-tile sums of the stored values
     x = out.float()
     assert torch.allclose(parts[1, :, 0], x[:, 160:320].sum(1), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize('B,H,C,N,ld', [(16, 64, 320, 320, 320), (8, 32, 640, 640, 640), (4, 16, 320, 320, 960), (2, 48, 320, 320, 320)])
+def test_groupnorm_folded_into_proj_in(dev, B, H, C, N, ld):
+    '''fd_groupnorm_fold_linear_f16 + fd_gemm_f16 with per-batch weights and bias (batch_stride_w / batch_stride_bias):
+    proj_in(GroupNorm(x)) from ONE statistics pass over x, no normalised activation.  vs fp32 torch (group_norm + linear)
+    and vs the unfused device path (fd_groupnorm + fd_gemm): the fold rounds W gamma rstd to fp16 instead of the normalised
+    activation -- same error class (mean error <= 1.5x the unfused path's).  Also: the statistics the per-sample GEMM
+    emits for the NEXT LayerNorm equal fd_ln_row_stats_f16 on its output (row index = batch * HW + m), x may be a column
+    slice of a wider matrix, 9 x 2^k rows per sample.'''
+    from flexdiffuse_amd import ops
+    HW, G = H * H, 32
+    g = torch.Generator().manual_seed(B * 1000 + C + H)
+    xw = (torch.randn((B * HW, ld), generator=g) * 1.5 + torch.randn((B, 1, ld), generator=g).repeat(1, HW, 1).reshape(B * HW, ld) * 0.7)
+    xw = xw.half()
+    x32 = xw[:, :C].float().reshape(B, HW, C)
+    w = torch.randn((N, C), generator=g) * C ** -0.5
+    b = torch.randn(N, generator=g) * 0.3
+    gamma, beta = 1.0 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    want = F.linear(F.group_norm(x32.permute(0, 2, 1), G, gamma, beta, 1e-6).permute(0, 2, 1), w, b).reshape(B * HW, N)
+    xd = xw.to(dev)
+    xa = ops.Act(xd[:, :C], B, H, H)
+    gf = ops.prep_gn_fold(w, b, gamma, beta, G, 1e-6, dev)
+    wb, bb = ops.gn_fold_linear(xa, gf)
+    k = ops.can_emit_row_stats(HW, N, C)
+    st = torch.full((B * HW, 2) if k == 1 else (k, B * HW, 2), float('nan'), dtype=torch.float32, device=dev) if k else None
+    got = ops.gemm_per_sample(xa.t, wb, bb, B, HW, ln_stats_out=st)
+    unf = ops.gemm(ops.groupnorm(xa, ops.f32(gamma, dev), ops.f32(beta, dev), G, 1e-6, False).t, ops.prep_linear(w, b, dev))
+    e_fold = (got.float().cpu() - want).abs()
+    e_unf = (unf.float().cpu() - want).abs()
+    scale = float(want.abs().max())
+    assert float(e_fold.max()) < 1e-2 * scale, (float(e_fold.max()), scale)
+    assert float(e_fold.mean()) <= 1.5 * float(e_unf.mean()) + 1e-6, (float(e_fold.mean()), float(e_unf.mean()))
+    if st is not None:
+        assert bool(torch.isfinite(st).all())
+        s2 = st if st.dim() == 2 else ops.ln_finalize_stats(st, N)
+        ref = ops.ln_row_stats(got)
+        assert float(((s2[:, 0] - ref[:, 0]).abs() / ref[:, 0]).max()) < 2e-4
+        assert float((s2[:, 1] - ref[:, 1]).abs().max()) < 2e-4 * max(1.0, float(ref[:, 1].abs().max()))
+    # without statistics: same values up to the tile choice
+    plain = ops.gemm_per_sample(xa.t, wb, bb, B, HW)
+    assert float((plain.float() - got.float()).abs().max()) <= 2e-3 * scale
+
+
+def test_per_batch_bias_is_refused_where_it_cannot_be_staged(dev):
+    from flexdiffuse_amd import ops
+    a = torch.zeros((512, 64), dtype=torch.float16, device=dev)
+    wb = torch.zeros((1, 64, 64), dtype=torch.float16, device=dev)
+    bb = torch.zeros((1, 64), dtype=torch.float32, device=dev)
+    with pytest.raises(ValueError):
+        ops.gemm_per_sample(a, wb, bb, 1, 512)      # batch_stride_bias needs batch > 1

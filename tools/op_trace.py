@@ -44,6 +44,8 @@ def describe(name, args):
     if isinstance(obj, ops.fd_xattn_desc):
         d = obj
         return f'xattn_q M{d.M} rep{d.n_rep}'
+    if name == 'fd_groupnorm_fold_linear_f16':
+        return f'groupnorm_fold B{args[3]} HW{args[4]} C{args[5]} N{args[11]}'
     if name.startswith('fd_groupnorm'):
         return f'groupnorm B{args[6]} HW{args[7]} C{args[8]} silu{args[11]}'
     if name == 'fd_ln_row_stats_f16':
