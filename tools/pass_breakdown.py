@@ -6,11 +6,13 @@ import bench
 from flexdiffuse_amd import Guide, SimpleGuide, build, dist as fdist, ops
 from flexdiffuse_amd.encode.clip import CLIPEncoder
 dev = torch.device('cuda:0')
-sds = build.synthetic_state_dicts('sd15', seed=0)
-pipe, clip, tok = build.build_models(sds, 'sd15', dev, vae_encoder=False)
+PRESET = sys.argv[1] if len(sys.argv) > 1 else 'sd15'   # python tools/pass_breakdown.py [preset] [image size]
+SIZE = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+sds = build.synthetic_state_dicts(PRESET, seed=0)
+pipe, clip, tok = build.build_models(sds, PRESET, dev, vae_encoder=False)
 g = Guide(clip, tok, device='cuda'); enc = CLIPEncoder(clip, tok)
 prompts = bench.synth_prompts(8); img = bench.synth_image(2, 512, 512)
-noise = fdist.global_noise(8, (4, 64, 64), 1337).to(dev)
+noise = fdist.global_noise(8, (4, SIZE // 8, SIZE // 8), 1337).to(dev)
 def sync(): torch.cuda.synchronize(); return time.time()
 for rep in range(3):
     t0 = sync()
@@ -23,7 +25,7 @@ for rep in range(3):
     lat = noise.clone()
     for t in pipe.scheduler.timesteps:
         eps = pipe.unet.forward_nhwc(lat, int(t), sg.stacked_embeds(), rep=2)
-        ops.cfg_ddim_step(lat, eps, 8, 4, 4096, True, 8.0, pipe.scheduler.step_coefficients(int(t))[:4], False)
+        ops.cfg_ddim_step(lat, eps, 8, 4, (SIZE // 8) ** 2, True, 8.0, pipe.scheduler.step_coefficients(int(t))[:4], False)
     t3 = sync()
     im = pipe.decode_latents(lat)
     t4 = sync()
