@@ -6,9 +6,10 @@ from flexdiffuse_amd import build, hip, ops
 from flexdiffuse_amd.unet import UNet2DConditionModel
 dev = torch.device('cuda:0')
 # python tools/op_trace.py [preset = sd15] [latent size = 64] [batch = 8]   (c4: sd15 96 4; c5: sd21 96 8)
-PRESET = sys.argv[1] if len(sys.argv) > 1 else 'sd15'
-LAT = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+_a = [v for v in sys.argv[1:] if not v.startswith('--')]
+PRESET = _a[0] if len(_a) > 0 else 'sd15'
+LAT = int(_a[1]) if len(_a) > 1 else 64
+B = int(_a[2]) if len(_a) > 2 else 8
 sds = build.synthetic_state_dicts(PRESET, seed=0, parts=('unet',))
 ucfg = build.configs(PRESET)[0]
 unet = UNet2DConditionModel(sds['unet'], ucfg, dev)
@@ -64,7 +65,17 @@ def traced(name, *args):
 
 
 hip.call = traced
-unet.forward_nhwc(x, 390, ctx, rep=2)
+if '--vae' in sys.argv:   # the VAE decode of B images instead of the UNet forward:  python tools/op_trace.py sd15 64 8 --vae
+    from flexdiffuse_amd.vae import AutoencoderKL
+    hip.call = orig
+    vae = AutoencoderKL(build.synthetic_state_dicts(PRESET, seed=0, parts=('vae',))['vae'], build.configs(PRESET)[1], dev, encoder=False)
+    for _ in range(2):
+        vae.decode_nhwc(x)
+    torch.cuda.synchronize()
+    hip.call = traced
+    vae.decode_nhwc(x)
+else:
+    unet.forward_nhwc(x, 390, ctx, rep=2)
 torch.cuda.synchronize()
 hip.call = orig
 agg = collections.OrderedDict()
