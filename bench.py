@@ -213,6 +213,36 @@ def best_kernel_leg(dev):
             'avg_launch_us': us, 'achieved': tflops, 'frac': tflops / MFMA_PEAK_TFLOPS}
 
 
+def devmon_collect(proc, t0: float, t1: float) -> dict:
+    '''Stops the sampler child (tools/devmon.py) and averages its samples inside [t0, t1] -- the timed region.
+    Makes "fast box / slow box" a number: the MFMA loops are power-capped, so the sustained gfx clock moves the
+    result by a few percent between boxes of one pool.'''
+    out = {'avg_sclk_mhz': None, 'avg_power_w': None, 'clock_samples': 0, 'clock_source': None}
+    if proc is None:
+        return out
+    try:
+        raw, _ = proc.communicate(input=b'', timeout=20)
+        rec = json.loads(raw.decode().strip().splitlines()[-1])
+    except Exception:      # noqa: BLE001 -- the sampler is best effort
+        try:
+            proc.kill()
+        except OSError:
+            pass
+        return out
+    out['clock_source'] = rec.get('source')
+    if rec.get('errors') and not rec.get('samples'):
+        out['clock_errors'] = rec['errors'][:2]
+    inside = [s for s in rec.get('samples', []) if t0 <= s[0] <= t1]
+    for key, col in (('avg_sclk_mhz', 1), ('avg_power_w', 2), ('avg_mclk_mhz', 3)):
+        vals = [s[col] for s in inside if len(s) > col and s[col] is not None]
+        if vals:
+            out[key] = sum(vals) / len(vals)
+            if col == 1:
+                out['min_sclk_mhz'], out['max_sclk_mhz'] = min(vals), max(vals)
+    out['clock_samples'] = len(inside)
+    return out
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -334,6 +364,9 @@ def main():
                     help='BASELINE configs[3] (c4): start from a synthetic init image of --size, '
                          '--strength 0.6 => int(steps * strength) UNet evaluations (pipeline/flex.py:181-221)')
     ap.add_argument('--strength', type=float, default=0.6)
+    ap.add_argument('--scheduler', default='ddim', choices=['ddim', 'pndm', 'lms'],
+                    help='ddim (BASELINE metric); pndm: the scheduler the reference harness actually passes '
+                         '(SD-v1-4 ships PNDM, utils.py:70; PLMS: steps + 1 UNet evaluations); lms: K-LMS')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -344,6 +377,17 @@ def main():
         sys.exit(2)
     if os.environ.get('FD_BENCH_PLUMBING') == '1':
         plumbing_rank(args)
+
+    # clock / power sampler: a child process (stdlib + amdsmi, never HIP), started before this process's
+    # first GPU call; rank 0's device only
+    devmon = None
+    if int(os.environ.get('RANK', '0')) == 0 and os.environ.get('FD_BENCH_DEVMON', '1') != '0':
+        try:
+            devmon = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', 'devmon.py')],
+                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                      env=dict(os.environ, FD_DEVMON_INDEX=os.environ.get('LOCAL_RANK', '0')))
+        except OSError:
+            devmon = None
 
     import torch
     os.environ['LOCAL_RANK'] = str(check_rank_device(int(os.environ.get('LOCAL_RANK', '0')), env_world))
@@ -365,7 +409,11 @@ def main():
     sds = build.synthetic_state_dicts(args.preset, seed=0)
     cfgs = build.configs(args.preset)
     pipe, clip, tok = build.build_models(sds, args.preset, dev, vae_encoder=args.img2img)
+    if args.scheduler != 'ddim':
+        from flexdiffuse_amd.scheduler import LMSDiscreteScheduler, PNDMScheduler
+        pipe.scheduler = PNDMScheduler() if args.scheduler == 'pndm' else LMSDiscreteScheduler()
     pipe.use_graph = args.graph
+    pipe.pause_gc = True          # with the gc.freeze() below: no collector pauses inside the timed loops
     pipe.use_plan = args.launch == 'plan' and not args.graph
     guide_ctx = Guide(clip, tok, device='cuda')
     enc = CLIPEncoder(clip, tok)
@@ -383,7 +431,13 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
         from make_c45_oracle import init_tensor
         init_image = init_tensor(3, hw).to(dev)
+        # the global batch's img2img draws in the pipeline's order (posterior sample, then add_noise rows)
+        # from one host generator; this rank's rows of the second
+        i2i_noise = fdist.global_img2img_noise(B * N, (4, hw // 8, hw // 8), 1337)[1][
+            fdist.shard_range(rank, N, B)].to(dev)
     ddim_evals = args.ddim_steps if not args.img2img else min(int(args.ddim_steps * args.strength), args.ddim_steps)
+    if args.scheduler == 'pndm':
+        ddim_evals += 1          # PLMS warm-up: the second timestep is evaluated twice
     t_setup = time.time() - t_setup
     gather = {'bytes_per_rank': 0, 'ms': 0.0, 'calls': 0}
 
@@ -391,10 +445,11 @@ def main():
         embeds = guide_ctx.embeds(prompt=prompts, guide=guide_img, **GUIDANCE[args.guidance])
         sg = SimpleGuide(enc, pipe.unet, 8.0, args.ddim_steps, embeds)
         if init_image is not None:
-            # img2img: VAE-encode the init image once, posterior sample and noise from a CPU
-            # generator (rank-offset seed: every rank draws its own B samples), t_start from strength
-            out = pipe(guide=sg, init_image=init_image, strength=args.strength,
-                       generator=torch.Generator('cpu').manual_seed(1337 + rank), output_type='np')
+            # img2img: VAE-encode the init image once; the posterior sample is the first draw of the
+            # same host generator on every rank, the add_noise rows are this rank's slice of the global
+            # draw (shard-invariant, like txt2img); t_start from strength
+            out = pipe(guide=sg, init_image=init_image, strength=args.strength, noise=i2i_noise,
+                       generator=torch.Generator('cpu').manual_seed(1337), output_type='np')
         else:
             out = pipe(guide=sg, init_size=(hw, hw), latents=noise, output_type='np')
         # one RCCL all-gather of the final latents and of the decoded images (identity at N=1)
@@ -431,7 +486,9 @@ def main():
     for k in range(args.steps):
         one_pass()
     sync()
-    elapsed = time.time() - t0
+    t1 = time.time()
+    elapsed = t1 - t0
+    device_state = devmon_collect(devmon, t0, t1)
     if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64,
                             device=dev if dist.get_backend() == 'nccl' else 'cpu')
@@ -476,8 +533,9 @@ def main():
         hip.prof_enable(False)
         for name, code in (('gemm', ops.FAMILY_GEMM), ('attention', ops.FAMILY_ATTENTION),
                            ('groupnorm', ops.FAMILY_GROUPNORM)):
-            ms, work, n = hip.prof_collect(code)
-            fam[name] = {'ms': max(ms - n * empty_ms, 0.0), 'raw_ms': ms, 'work': work, 'launches': n}
+            ms, work, executed, n = hip.prof_collect2(code)
+            fam[name] = {'ms': max(ms - n * empty_ms, 0.0), 'raw_ms': ms, 'work': work, 'executed': executed,
+                         'launches': n}
     elif dist.is_initialized():
         one_pass(time_gather=True)       # every rank takes part in the extra pass's all-gather
         torch.cuda.synchronize()
@@ -488,6 +546,7 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         g, att, gn = fam['gemm'], fam['attention'], fam['groupnorm']
         achieved = (g['work'] / (g['ms'] * 1e-3)) / 1e12 if g['ms'] > 0 else 0.0
+        executed = (g['executed'] / (g['ms'] * 1e-3)) / 1e12 if g['ms'] > 0 else 0.0
         fam_sum = EVENT_STRIDE * (g['ms'] + att['ms'] + gn['ms'])
         # HBM bytes of the dominant kernel (level-0 conv3x3) from its PMC pass: rocprofv3 cannot
         # run inside this process, so the committed per-launch measurement is reported with its
@@ -509,7 +568,7 @@ def main():
             except (OSError, KeyError, ValueError):
                 continue
         fpi = flops_per_image(args.preset, hw, ddim_evals)
-        headline = (args.preset == 'sd15' and hw == 512 and args.ddim_steps == 50
+        headline = (args.preset == 'sd15' and hw == 512 and args.ddim_steps == 50 and args.scheduler == 'ddim'
                     and args.guidance == 'linear' and B == 8 and not args.img2img)
         cfg_name = {('sd15', 'linear', False): 'BASELINE configs[1]',
                     ('sd15', 'clustered_threshold', False): 'BASELINE configs[2] guidance',
@@ -518,7 +577,7 @@ def main():
                         (args.preset, args.guidance, args.img2img), 'non-headline')
         model = {'sd15': 'SD1.5', 'sd21': 'SD2.1 + OpenCLIP ViT-H/14 guide'}.get(args.preset, args.preset)
         mode = (f'img2img strength {args.strength} ({ddim_evals} of {args.ddim_steps} DDIM steps)'
-                if args.img2img else f'{args.ddim_steps}-step DDIM')
+                if args.img2img else f'{args.ddim_steps}-step {args.scheduler.upper()}')
         line = {
             'metric': '512x512 50-step images/sec/node (SD1.5, batch=8/GPU, Linear image guidance)'
                       if headline else f'{hw}x{hw} {mode} images/sec/node ({model}, '
@@ -531,7 +590,8 @@ def main():
                                    f'guidance, CFG 8, batch={B}/GPU ({cfg_name})',
                        'images_per_step': B * N, 'parallelism': f'seed-sharded x{N}',
                        'preset': args.preset, 'guidance': args.guidance, 'img2img': args.img2img,
-                       'unet_evaluations_per_image': ddim_evals, 'launch': margin['launch']},
+                       'unet_evaluations_per_image': ddim_evals, 'launch': margin['launch'],
+                       'scheduler': args.scheduler},
             # ranks that took part in an RCCL (torch.distributed "nccl") process group; 0 for any
             # other backend (gloo plumbing runs) and for an undistributed N=1 run
             'rccl_ranks': dist.get_world_size() if dist.is_initialized() and dist.get_backend() == 'nccl' else 0,
@@ -544,7 +604,12 @@ def main():
             'roofline': {
                 'bound': 'mfma', 'kernel': 'k_gemm_f16 (implicit-GEMM conv3x3 / GEMM family)',
                 'achieved': achieved, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_of': traffic_of,
+                'frac': achieved / MFMA_PEAK_TFLOPS,
+                # MACs the kernels really issued / time / peak: `achieved` prices every launch at the ALGORITHMIC work of
+                # the op it implements (a parity-decomposed upsample convolution executes 4/9 of its 3x3 MACs, a Winograd
+                # F(2x2,3x3) convolution 4/9 as well); this is the hardware-side rate of the same launches
+                'executed': executed, 'executed_frac': executed / MFMA_PEAK_TFLOPS,
+                'traffic': traffic, 'traffic_of': traffic_of,
                 'traffic_other_kernels': traffic_other,
                 # sums over the sampled launches (every EVENT_STRIDE-th of each family) of one
                 # untimed pass, empty-bracket cost subtracted, scaled to the pass
@@ -564,7 +629,7 @@ def main():
                 'end_to_end_frac_of_mfma_roofline':
                     (value / N) * fpi / (MFMA_PEAK_TFLOPS * 1e12) if fpi else None,
             },
-            'device': info, 'setup_s': t_setup,
+            'device': dict(info, **device_state), 'setup_s': t_setup,
         }
         line['roofline']['best_kernel'] = best_kernel_leg(dev)
         line['roofline']['frac_best_kernel'] = line['roofline']['best_kernel']['frac']

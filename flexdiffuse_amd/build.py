@@ -19,7 +19,12 @@ import dataclasses
 MINI2_UNET = dataclasses.replace(W.MINI_UNET, num_heads=(5, 10, 20), use_linear_projection=True,
                                  prediction_type='v_prediction')
 
+# the mini model with a text tower wide enough for a real byte-level BPE vocabulary (512 byte symbols + merges +
+# the two specials): what the from-disk tests write as vocab.json / merges.txt
+MINI_BPE_CLIP = dataclasses.replace(W.MINI_CLIP, text=dataclasses.replace(W.MINI_CLIP.text, vocab_size=1024))
+
 PRESETS = {
+    'mini_bpe': (W.MINI_UNET, W.MINI_VAE, MINI_BPE_CLIP),
     'sd15': (W.SD15_UNET, W.SD_VAE, W.CLIP_VIT_L14),
     'mini2': (MINI2_UNET, W.MINI_VAE, W.MINI_CLIP),
     'sd21': (W.SD21_UNET, W.SD_VAE, W.CLIP_VIT_H14),
@@ -136,6 +141,20 @@ def load_tokenizer(tokenizer_dir: str):
     (encode/clip.py:57-63).'''
     from .tokenizer import CLIPBPETokenizer
     return CLIPBPETokenizer.from_pretrained(tokenizer_dir)
+
+
+def from_directories(sd_dir: str, clip_dir: str, tokenizer_dir: Optional[str] = None, preset: str = 'sd15',
+                     device='cuda', **kw):
+    '''(pipeline, clip, tokenizer) from files on disk -- the local-files half of the reference's
+    `Runner.__init__` (utils.py:59-71: CLIPModel.from_pretrained + StableDiffusionPipeline.from_pretrained
+    -> FlexPipeline(sd.vae, clip, sd.tokenizer, sd.unet, sd.scheduler)).  The tokenizer comes from
+    `tokenizer_dir`, else from `sd_dir`/tokenizer (where the SD checkpoint keeps it).'''
+    import os
+    sds = load_state_dicts(sd_dir, clip_dir, preset)
+    tdir = tokenizer_dir or os.path.join(sd_dir, 'tokenizer')
+    if not os.path.exists(os.path.join(tdir, 'vocab.json')):
+        raise FileNotFoundError(f'no vocab.json under {tdir}: pass tokenizer_dir')
+    return build_models(sds, preset, device, tokenizer=load_tokenizer(tdir), **kw)
 
 
 def configs(preset: str):

@@ -52,7 +52,9 @@ void fd_plan_push(std::function<int(void*)> op);
 #endif
 
 // optional per-launch HIP-event timing of a kernel family (bench.py roofline leg)
-void fd_prof_begin(int family, hipStream_t s, double work);
+// `work`: the ALGORITHMIC FLOPs / bytes of the op the launch implements; `executed` (< 0: same as work): what the
+// kernel really issues (the parity-decomposed upsample convolution runs 4/9 of its 3x3 MACs)
+void fd_prof_begin(int family, hipStream_t s, double work, double executed = -1.0);
 void fd_prof_end(int family, hipStream_t s);
 
 typedef _Float16 half_t;

@@ -1718,13 +1718,14 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // priced at the ALGORITHMIC work of the op it implements: the phase-decomposed upsample convolution (batch 4, K = 4 Cin)
     // stands for a 3x3 convolution over the 4 M upsampled pixels (K = 9 Cin), of which it executes 4/9 of the MACs
-    const double flops = (d->conv && d->upsample2x == 2 ? 2.25 : 1.0) * 2.0 * (double)d->M * d->N * ((double)d->K + d->K2) * batch;
+    const double flops_exec = 2.0 * (double)d->M * d->N * ((double)d->K + d->K2) * batch;
+    const double flops = (d->conv && d->upsample2x == 2 ? 2.25 : 1.0) * flops_exec;
     g.split_k = 1;
     g.bias_lds = g_bias_lds;
     g.ws = (float*)d->workspace;
     int rc;
     if (d->trans_out) {
-        fd_prof_begin(FD_FAMILY_GEMM, st, flops);
+        fd_prof_begin(FD_FAMILY_GEMM, st, flops, flops_exec);
         // 128x160 with 8 waves where 160 | N and the rows fill the chip: -16..18 % on the 64x64 / 32x32
         // self-attention V projections (tools/ab_vt.py; 256x160 / 16 waves is no better, 16x16 maps tie).
         // FD_GEMM_VT_TILE=0: the 128x64 / 4-wave tile everywhere (A/B)
@@ -1906,7 +1907,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     if (geglu && (best_tile == 2 || best_tile == 5 || best_tile == 7 || best_tile == 9 || best_tile == 12 || best_tile == 13 || best_tile == 16 || best_tile == 20 || best_tile == 23)) best_tile = 1;
     g.split_k = best_split;
     g.tap_fast = g.mode == MODE_CONV && (g_tap_fast == 2 || (g_tap_fast == 1 && best_tile == 16));
-    fd_prof_begin(FD_FAMILY_GEMM, st, flops);
+    fd_prof_begin(FD_FAMILY_GEMM, st, flops, flops_exec);
     if (g.ln_stats && !(best_tile == 9 || best_tile == 10 || (best_tile >= 12 && best_tile <= 16) || best_tile == 20 || best_tile == 23)) {
         // small problems: the generic epilogue with the fold compiled in (64x64 for few rows)
         rc = best_tile == 4 ? launch_mode<64, 64, false, false, 2, 2, 2, 7>(g, batch, st)

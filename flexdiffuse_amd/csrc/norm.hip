@@ -386,10 +386,13 @@ static bool gn_try_slab(const void* x, void* y, const float* gamma, const float*
 // ---------------------------------------------------------------------------------------
 #define GNF_ROWS 16
 __global__ __launch_bounds__(256) void k_gn_fold_linear(const float* __restrict__ part, int nchunk_stats, int HW, int C, int G, float eps,
-                                                        const half_t* __restrict__ wg, const float* __restrict__ S,
+                                                        const half_t* __restrict__ wg,
                                                         const float* __restrict__ biasf, int N, half_t* __restrict__ w_out,
                                                         float* __restrict__ bias_out) {
-    __shared__ float rstd_s[64], mr_s[64];   // G <= 64
+    __shared__ float rstd_s[64], mean_s[64];   // G <= 64
+    __shared__ float gsum_s[GNF_ROWS][64];
+    extern __shared__ __align__(16) unsigned char gnf_lds[];   // the block's ROUNDED output weights, fp16 [GNF_ROWS][C]
+    half_t* wr = reinterpret_cast<half_t*>(gnf_lds);
     const int b = blockIdx.y, tid = threadIdx.x;
     if (tid < G) {   // the combine of k_gn_apply: partial sums in a fixed order, fp64
         double s = 0.0, q = 0.0;
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(256) void k_gn_fold_linear(const float* __restrict_
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)eps);
         rstd_s[tid] = (float)rstd;
-        mr_s[tid] = (float)(mean * rstd);
+        mean_s[tid] = (float)mean;
     }
     __syncthreads();
     const int n0 = blockIdx.x * GNF_ROWS, rows = min(GNF_ROWS, N - n0);
@@ -417,11 +420,24 @@ __global__ __launch_bounds__(256) void k_gn_fold_linear(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (half_t)((float)v[k] * rstd_s[(cc * 8 + k) / cpg]);
         *reinterpret_cast<half8*>(w_out + ((size_t)b * N + n0 + r) * C + cc * 8) = o;
+        *reinterpret_cast<half8*>(wr + (size_t)r * C + cc * 8) = o;
     }
+    __syncthreads();
+    // The consumer GEMM computes sum_c w_out[c] x[c] + bias with the RE-ROUNDED w_out, so the mean term must be taken
+    // over those same fp16 values -- bias = biasf - sum_g mean_g * (sum_{c in g} w_out[c]) -- for the group mean to
+    // cancel exactly whatever its size relative to the spread (a mean of 10 sigma would otherwise leave 10 * 2^-11 of
+    // sigma per weight instead of 2^-11).  Fixed summation order: deterministic.
+    for (int i = tid; i < rows * G; i += 256) {
+        const int r = i / G, g = i - r * G;
+        const half_t* src = wr + (size_t)r * C + g * cpg;
+        float acc = 0.f;
+        for (int c = 0; c < cpg; ++c) acc += (float)src[c];
+        gsum_s[r][g] = acc;
+    }
+    __syncthreads();
     if (tid < rows) {
-        const float* Sn = S + (size_t)(n0 + tid) * G;
         float acc = biasf[n0 + tid];
-        for (int g = 0; g < G; ++g) acc = fmaf(-mr_s[g], Sn[g], acc);
+        for (int g = 0; g < G; ++g) acc = fmaf(-mean_s[g], gsum_s[tid][g], acc);
         bias_out[(size_t)b * N + n0 + tid] = acc;
     }
 }
@@ -444,10 +460,10 @@ static void gn_stats_shape(int B, int HW, int C, int* PL, int* threads, int* nch
 }
 
 extern "C" int fd_groupnorm_fold_linear_f16(const void* x, int ldx, float* ws, int B, int HW, int C, int G, float eps,
-                                            const void* wg, const float* S, const float* biasf, int N,
+                                            const void* wg, const float* biasf, int N,
                                             void* w_out, float* bias_out, void* stream) {
-    FD_PLAN(fd_groupnorm_fold_linear_f16(x, ldx, ws, B, HW, C, G, eps, wg, S, biasf, N, w_out, bias_out, fd_s_));
-    FD_CHECK_ARG(x && ws && wg && S && biasf && w_out && bias_out, FD_EINVAL, "fd_groupnorm_fold_linear_f16: null pointer");
+    FD_PLAN(fd_groupnorm_fold_linear_f16(x, ldx, ws, B, HW, C, G, eps, wg, biasf, N, w_out, bias_out, fd_s_));
+    FD_CHECK_ARG(x && ws && wg && biasf && w_out && bias_out, FD_EINVAL, "fd_groupnorm_fold_linear_f16: null pointer");
     FD_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && N > 0, FD_EINVAL, "fd_groupnorm_fold_linear_f16: bad dims");
     FD_CHECK_ARG(C % 8 == 0 && C % G == 0 && G <= 64 && C / 8 <= 1024, FD_ESHAPE,
                  "fd_groupnorm_fold_linear_f16: C=%d must be a multiple of 8 and of G=%d (G <= 64)", C, G);
@@ -459,11 +475,13 @@ extern "C" int fd_groupnorm_fold_linear_f16(const void* x, int ldx, float* ws, i
     gn_stats_shape(B, HW, C, &PL, &threads, &nchunk, &ppc);
     const size_t lds1 = (size_t)PL * C * 2 * sizeof(float);
     FD_CHECK_ARG(lds1 <= 64 * 1024, FD_ESHAPE, "fd_groupnorm_fold_linear_f16: stats LDS too large");
+    const size_t lds2 = (size_t)GNF_ROWS * C * sizeof(half_t);
+    FD_CHECK_ARG(lds2 <= 48 * 1024, FD_ESHAPE, "fd_groupnorm_fold_linear_f16: C=%d too wide for the fold kernel's weight tile", C);
     // priced as the statistics read only (2 B/element): the apply pass it replaces is gone
     fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 2.0);
     hipLaunchKernelGGL(k_gn_stats, dim3(nchunk, B), dim3(threads), lds1, st, (const half_t*)x, ws, HW, C, G, PL, ppc, ldx);
-    hipLaunchKernelGGL(k_gn_fold_linear, dim3(fd_cdiv(N, GNF_ROWS), B), dim3(256), 0, st, (const float*)ws, nchunk, HW, C, G, eps,
-                       (const half_t*)wg, S, biasf, N, (half_t*)w_out, bias_out);
+    hipLaunchKernelGGL(k_gn_fold_linear, dim3(fd_cdiv(N, GNF_ROWS), B), dim3(256), lds2, st, (const float*)ws, nchunk, HW, C, G, eps,
+                       (const half_t*)wg, biasf, N, (half_t*)w_out, bias_out);
     fd_prof_end(FD_FAMILY_GROUPNORM, st);
     FD_CHECK_LAUNCH("k_gn_stats/k_gn_fold_linear");
     return FD_OK;

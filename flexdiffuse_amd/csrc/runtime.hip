@@ -37,7 +37,7 @@ extern "C" int fd_device_info(int device, int* cu_count, int* clock_khz, int64_t
 // ---- kernel-family timing recorder -------------------------------------------------
 struct ProfRec {
     int family;
-    double work;
+    double work, executed;
     hipEvent_t e0, e1;
 };
 static std::mutex g_prof_mu;
@@ -63,7 +63,7 @@ static hipEvent_t prof_event() {
     return e;
 }
 
-void fd_prof_begin(int family, hipStream_t s, double work) {
+void fd_prof_begin(int family, hipStream_t s, double work, double executed) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     const int f = family & 7;
@@ -72,6 +72,7 @@ void fd_prof_begin(int family, hipStream_t s, double work) {
     ProfRec r;
     r.family = family;
     r.work = work;
+    r.executed = executed < 0 ? work : executed;
     r.e0 = prof_event();
     r.e1 = prof_event();
     hipEventRecord(r.e0, s);
@@ -127,10 +128,17 @@ extern "C" int fd_prof_calibrate(int pairs, double* ms_per_empty_pair, void* str
 
 // Sums (after synchronising the recorded events) the elapsed ms, the declared work
 // (FLOPs or bytes) and the launch count of `family`; then forgets those records.
+extern "C" int fd_prof_collect2(int family, double* total_ms, double* total_work, double* total_executed,
+                                int64_t* launches);
 extern "C" int fd_prof_collect(int family, double* total_ms, double* total_work,
                                int64_t* launches) {
+    return fd_prof_collect2(family, total_ms, total_work, nullptr, launches);
+}
+
+extern "C" int fd_prof_collect2(int family, double* total_ms, double* total_work, double* total_executed,
+                                int64_t* launches) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    double ms = 0, work = 0;
+    double ms = 0, work = 0, executed = 0;
     int64_t n = 0;
     std::vector<ProfRec> keep;
     for (auto& r : g_prof) {
@@ -143,6 +151,7 @@ extern "C" int fd_prof_collect(int family, double* total_ms, double* total_work,
             hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
             ms += t;
             work += r.work;
+            executed += r.executed;
             ++n;
         }
         g_pool.push_back(r.e0);
@@ -151,6 +160,7 @@ extern "C" int fd_prof_collect(int family, double* total_ms, double* total_work,
     g_prof.swap(keep);
     if (total_ms) *total_ms = ms;
     if (total_work) *total_work = work;
+    if (total_executed) *total_executed = executed;
     if (launches) *launches = n;
     return FD_OK;
 }

@@ -53,6 +53,19 @@ def global_noise(total: int, shape: Sequence[int], seed: int) -> torch.Tensor:
                        dtype=torch.float32)
 
 
+def global_img2img_noise(total: int, shape: Sequence[int], seed: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    '''img2img draws of the whole global batch in the pipeline's order from ONE host generator
+    (reference pipeline/flex.py:189-214): the VAE posterior sample (1, *shape) -- shared by every
+    sample, the reference repeats the encoded latent -- then the add_noise draw (total, *shape).
+    Every rank calls this with the same seed and passes its rows of the second tensor to
+    `FlexPipeline.__call__(noise=...)` together with a generator seeded with `seed` (whose first draw
+    is then the same posterior sample on every rank): images do not depend on the world size.'''
+    g = torch.Generator('cpu').manual_seed(seed)
+    posterior = torch.randn((1,) + tuple(shape), generator=g, dtype=torch.float32)
+    noise = torch.randn((total,) + tuple(shape), generator=g, dtype=torch.float32)
+    return posterior, noise
+
+
 def shard(items, rank: int, world_size: int, per_rank: int):
     return items[shard_range(rank, world_size, per_rank)]
 

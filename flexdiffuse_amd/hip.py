@@ -36,6 +36,7 @@ _SIGNATURES = {
     'fd_prof_enable': (c_int, [c_int]),
     'fd_prof_set_stride': (c_int, [c_int]),
     'fd_prof_collect': (c_int, [c_int, P, P, P]),
+    'fd_prof_collect2': (c_int, [c_int, P, P, P, P]),
     'fd_prof_calibrate': (c_int, [c_int, P, P]),
     'fd_guidance_workspace_floats': (c_int64, [c_int, c_int, c_int]),
     'fd_guidance_map': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -55,7 +56,7 @@ _SIGNATURES = {
     'fd_layernorm_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'fd_ln_row_stats_f16': (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
     'fd_ln_finalize_stats_f32': (c_int, [P, P, c_int, c_int, c_int, c_float, P]),
-    'fd_groupnorm_fold_linear_f16': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_float, P, P, P, c_int, P, P, P]),
+    'fd_groupnorm_fold_linear_f16': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_float, P, P, c_int, P, P, P]),
     'fd_softmax_rows_f16': (c_int, [P, c_int, c_int, c_int, c_float, P]),
     'fd_nchw_f32_to_nhwc_f16': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'fd_nhwc_f32_to_nchw_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P]),
@@ -79,7 +80,7 @@ _SIGNATURES = {
     'fd_cast_f16_to_f32': (c_int, [P, P, c_int64, P]),
 }
 
-ABI_VERSION = 8   # FD_ABI_VERSION in include/flexdiffuse_hip.h
+ABI_VERSION = 9   # FD_ABI_VERSION in include/flexdiffuse_hip.h
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -225,3 +226,10 @@ def prof_collect(family: int):
     ms, work, n = c_double(0), c_double(0), c_int64(0)
     call('fd_prof_collect', family, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
     return ms.value, work.value, n.value
+
+
+def prof_collect2(family: int):
+    '''(ms, declared work, executed work, launches) of the sampled launches of `family`.'''
+    ms, work, ex, n = c_double(0), c_double(0), c_double(0), c_int64(0)
+    call('fd_prof_collect2', family, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(ex), ctypes.byref(n))
+    return ms.value, work.value, ex.value, n.value

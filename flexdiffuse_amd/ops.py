@@ -499,13 +499,21 @@ def xattn_q(x: torch.Tensor, w: LinW, ln_stats: torch.Tensor, images: Tuple[torc
 
 # ---------------------------------------------------------------------------------- norms
 _gn_ws = {}
+_gn_ws_retired = []    # outgrown scratch buffers: never freed (see _gn_workspace)
 
 
 def _gn_workspace(B: int, G: int, dev) -> torch.Tensor:
+    '''Per-(device, slot) GroupNorm scratch, grow-only.  A recorded launch plan (hip.Plan) replays raw
+    device addresses, this one included, and the plan cannot see a later reallocation -- so an outgrown
+    buffer is RETIRED, not freed: its address stays valid (and private to GroupNorm launches) for every
+    plan that recorded it.  A buffer is a few KB (B x G partial sums); growth happens a handful of times
+    per process (first call per batch size).'''
     n = hip.lib().fd_groupnorm_workspace_floats(B, G)
     key = (dev.index if dev.index is not None else 0, WS_SLOT)
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < n:
+        if ws is not None:
+            _gn_ws_retired.append(ws)
         ws = torch.empty(n, dtype=torch.float32, device=dev)
         _gn_ws[key] = ws
     return ws
@@ -526,7 +534,6 @@ def groupnorm(x: Act, gamma: torch.Tensor, beta: torch.Tensor, G: int, eps: floa
 class GNFold:
     '''Model constants of a GroupNorm folded into the linear layer behind it (prep_gn_fold).'''
     wg: torch.Tensor      # fp16 [N][C] = W diag(gamma)
-    S: torch.Tensor       # fp32 [N][G]: group sums of the ROUNDED wg (so the mean cancels exactly)
     biasf: torch.Tensor   # fp32 [N] = bias + W beta
     G: int
     eps: float
@@ -540,9 +547,8 @@ def prep_gn_fold(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor
     w = w.reshape(w.shape[0], -1).float()
     N, C = w.shape
     wg = (w * gamma.float()[None, :]).half()
-    S = wg.float().reshape(N, G, C // G).sum(-1)
     biasf = (b.float() if b is not None else torch.zeros(N)) + w @ beta.float()
-    return GNFold(wg.contiguous().to(dev), S.contiguous().to(dev), biasf.contiguous().to(dev), G, eps, N, C)
+    return GNFold(wg.contiguous().to(dev), biasf.contiguous().to(dev), G, eps, N, C)
 
 
 def gn_fold_supported(B: int, HW: int, N: int) -> bool:
@@ -559,7 +565,7 @@ def gn_fold_linear(x: Act, gf: GNFold) -> Tuple[torch.Tensor, torch.Tensor]:
     bb = _empty((x.B, gf.N), torch.float32, x.t)
     ws = _gn_workspace(x.B, gf.G, x.t.device)
     hip.call('fd_groupnorm_fold_linear_f16', x.t.data_ptr(), x.t.stride(0), ws.data_ptr(), x.B, x.HW, gf.C, gf.G, gf.eps,
-             gf.wg.data_ptr(), gf.S.data_ptr(), gf.biasf.data_ptr(), gf.N, wb.data_ptr(), bb.data_ptr(), hip.stream())
+             gf.wg.data_ptr(), gf.biasf.data_ptr(), gf.N, wb.data_ptr(), bb.data_ptr(), hip.stream())
     return wb, bb
 
 

@@ -21,6 +21,7 @@ from __future__ import annotations
 import contextlib
 import gc
 import inspect
+import warnings
 from typing import List, Optional, Tuple, Union
 
 import numpy as np
@@ -62,6 +63,16 @@ class StableDiffusionPipelineOutput():
 class FlexPipeline():
     def __init__(self, vae, clip, tokenizer, unet, scheduler):
         scheduler = scheduler.set_format('pt')
+        # pipeline/flex.py:57-70: a scheduler config that HAS a steps_offset other than 1 is rewritten
+        # to 1 (with a DeprecationWarning) through the scheduler's `_internal_dict`
+        cfg = scheduler.config
+        if hasattr(cfg, 'steps_offset') and cfg['steps_offset'] != 1:
+            warnings.warn(f'The configuration file of this scheduler: {scheduler} is outdated. '
+                          f'`steps_offset` should be set to 1 instead of {cfg["steps_offset"]}.',
+                          DeprecationWarning)
+            fixed = dict(cfg)
+            fixed['steps_offset'] = 1
+            setattr(scheduler, '_internal_dict', type(cfg)(fixed))
         self.vae = vae
         self.clip = clip
         self.tokenizer = tokenizer
@@ -80,11 +91,19 @@ class FlexPipeline():
         # (hip.Plan): identical kernels / order / results to the eager front, ~1/5 of its host time
         self.use_plan = True
         self._plans = {}
+        # opt-in (bench.py, Runner(pause_gc=True)): keep the cyclic GC off across the denoising loop.
+        # Off by default: a drop-in must not change interpreter-global state of someone else's process.
+        self.pause_gc = False
 
     @classmethod
-    def from_pretrained(cls, *a, **k):
-        raise NotImplementedError('no checkpoints are available offline; build the model '
-                                  'containers from a state dict (see flexdiffuse_amd.build)')
+    def from_pretrained(cls, sd_dir, clip_dir=None, tokenizer_dir=None, preset: str = 'sd15',
+                        device='cuda', **_):
+        '''Local files only (there is no hub access): `sd_dir` is a diffusers-layout checkpoint
+        directory (unet/, vae/, optionally tokenizer/), `clip_dir` a CLIPModel directory -- what the
+        reference's `Runner.__init__` obtains from the hub (utils.py:59-71).  See
+        `flexdiffuse_amd.build.from_directories`.'''
+        from .. import build
+        return build.from_directories(sd_dir, clip_dir, tokenizer_dir, preset=preset, device=device)[0]
 
     def to(self, device):
         self.device = torch.device(device)
@@ -114,8 +133,18 @@ class FlexPipeline():
         img = self.vae.decode_nhwc(latents, scale=1.0 / VAE_SCALE)
         return ops.nhwc_to_nchw(img.t, img.B, 3, img.H, img.W, 0.5, 0.5, True)
 
+    def _decode_generic(self, latents: torch.Tensor) -> torch.Tensor:
+        '''pipeline/flex.py:116-120 for any object with the diffusers surface `decode(z).sample`
+        (NCHW): scale, decode, (x/2 + 0.5).clamp(0, 1) -- the affine + clamp on the library's layout
+        kernel with the NCHW tensor read as B*C one-channel maps.'''
+        z = ops.axpby(latents.to(self.device, torch.float32), None, 1.0 / VAE_SCALE, 0.0)
+        image = self.vae.decode(z).sample.to(torch.float32).contiguous()
+        B, C, H, W = image.shape
+        return ops.nhwc_to_nchw(image.view(-1, 1), B * C, 1, H, W, 0.5, 0.5, True).view(B, C, H, W)
+
     def _latents_to_image(self, latents: torch.Tensor, pil: bool = True):
-        image = self.decode_latents(latents)
+        image = self.decode_latents(latents) if hasattr(self.vae, 'decode_nhwc') \
+            else self._decode_generic(latents)
         self.last_images = image
         image = image.cpu().permute(0, 2, 3, 1).numpy()
         if pil:
@@ -219,7 +248,12 @@ class FlexPipeline():
                  output_type: str = 'pil',
                  return_dict: bool = True,
                  debug: bool = False,
-                 latents: Optional[torch.Tensor] = None):
+                 latents: Optional[torch.Tensor] = None,
+                 noise: Optional[torch.Tensor] = None):
+        '''Arguments and defaults of pipeline/flex.py:127-137, plus two optional tensors for sharded
+        runs (flexdiffuse_amd.dist): `latents` -- txt2img initial latents (B,4,h,w) instead of the
+        pipeline's own randn; `noise` -- img2img add_noise rows (B,4,h,w) instead of its own randn
+        (the rank's rows of the global batch's draw, `dist.global_img2img_noise`).'''
         if strength < 0 or strength > 1:
             raise ValueError(
                 f'The value of strength should in [0.0, 1.0] but is {strength}')
@@ -242,7 +276,12 @@ class FlexPipeline():
                 t_noise = guide.steps - init_timestep     # pipeline/flex.py:200-204: an index
             else:
                 t_noise = int(self.scheduler.timesteps[-init_timestep])
-            noise = self._randn(init_latents.shape, generator)
+            # one level per sample, as a long tensor (pipeline/flex.py:201-209); built on the host
+            t_noise = torch.tensor([t_noise] * batch_size, dtype=torch.long)
+            noise = self._randn(init_latents.shape, generator) if noise is None \
+                else noise.to(self.device, torch.float32)
+            if tuple(noise.shape) != tuple(init_latents.shape):
+                raise ValueError(f'noise {tuple(noise.shape)} does not match the latents {tuple(init_latents.shape)}')
             init_latents = self.scheduler.add_noise(init_latents, noise, t_noise)
             t_start = max(guide.steps - init_timestep + offset, 0)
         else:
@@ -265,6 +304,10 @@ class FlexPipeline():
                  and isinstance(self.scheduler, DDIMScheduler) and not eta
                  and hasattr(self.unet, 'forward_nhwc'))
         B, C, H, W = latents.shape
+        # SimpleGuide with ANY other scheduler (PNDM -- what the reference's Runner passes, utils.py:70 -- LMS, DDIM with
+        # eta): the UNet forward still comes from the launch plan / graph; only the scheduler arithmetic stays generic
+        planned = (not fused and type(guide).noise_pred is SimpleGuide.noise_pred and hasattr(self.unet, 'forward_nhwc')
+                   and (self.use_graph or self.use_plan) and not debug)
         if fused and (self.use_graph or self.use_plan) and not debug:
             # persistent latent buffer: the captured UNet graph / recorded plan reads this address
             latents = self.loop_latents(latents)
@@ -272,7 +315,7 @@ class FlexPipeline():
         # The host only has to stay ahead of the device queue.  A generation-2 collection of the
         # cyclic GC walks every tracked object of the process (~175 k with the SD1.5 weights:
         # ~40 ms) and drains that queue, so collections wait until the images are decoded.
-        with _gc_paused():
+        with (_gc_paused() if self.pause_gc else contextlib.nullcontext()):
             for i, t in enumerate(self.progress_bar(self.scheduler.timesteps[t_start:])):
                 if fused:
                     cfg = guide.classifier_free_guidance
@@ -292,12 +335,22 @@ class FlexPipeline():
                         t_index = t_start + i
                         sigma = float(self.scheduler.sigmas[t_index])
                         model_input = ops.axpby(latents, None, 1.0 / ((sigma ** 2 + 1) ** 0.5), 0.0)
-                    noise_pred = guide.noise_pred(model_input, t)
+                    if planned:
+                        cfg = guide.classifier_free_guidance
+                        eps = self._unet_eps(self.loop_latents(model_input), float(t), guide.stacked_embeds(),
+                                             2 if cfg else 1)
+                        noise_pred = torch.empty((B, C, H, W), dtype=torch.float32, device=latents.device)
+                        ops.cfg_ddim_step(None, eps, B, C, H * W, cfg, guide.guidance, do_step=False, eps_out=noise_pred)
+                    else:
+                        noise_pred = guide.noise_pred(model_input, t)
                     latents = self.scheduler.step(noise_pred, t_index, latents,
                                                   **extra_step_kwargs).prev_sample
                 if all_latents is not None:
                     all_latents.append(latents)
-            self.last_latents = latents
+            # the fused loop ran on the persistent per-shape buffer, which the next call overwrites:
+            # hand out a copy, so a caller holding `pipe.last_latents` keeps the values it read
+            persistent = any(latents is b for b in self._lat_bufs.values())
+            self.last_latents = latents.clone() if persistent else latents
 
             if all_latents:
                 batches = [self._latents_to_image(l, output_type == 'pil') for l in all_latents]

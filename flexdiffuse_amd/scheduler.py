@@ -19,10 +19,34 @@ from . import ops
 
 
 class _Config(dict):
-    __getattr__ = dict.__getitem__
+    '''Keys also read as attributes, like diffusers' FrozenDict (the reference tests
+    `hasattr(scheduler.config, 'steps_offset')`, pipeline/flex.py:57).'''
+
+    def __getattr__(self, key):
+        try:
+            return self[key]
+        except KeyError:
+            raise AttributeError(key) from None
 
 
-class DDIMScheduler():
+class _Configured():
+    '''`config` reads `_internal_dict`, the attribute the reference's pipeline constructor replaces
+    when it rewrites an outdated `steps_offset` (pipeline/flex.py:68-70).  A scheduler built with
+    `steps_offset=0` carries NO such key -- diffusers 0.3.0, which the reference pins, has none, and
+    the constructor's rewrite only fires on a key that exists.'''
+    _internal_dict: _Config
+
+    @property
+    def config(self) -> _Config:
+        return self._internal_dict
+
+    def _set_config(self, steps_offset: int = 0, **kw):
+        if steps_offset:
+            kw['steps_offset'] = steps_offset
+        self._internal_dict = _Config(**kw)
+
+
+class DDIMScheduler(_Configured):
     def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085,
                  beta_end: float = 0.012, beta_schedule: str = 'scaled_linear',
                  clip_sample: bool = False, set_alpha_to_one: bool = False, steps_offset: int = 0,
@@ -41,10 +65,10 @@ class DDIMScheduler():
         self.final_alpha_cumprod = np.float32(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
         # the pinned diffusers 0.3.0 has no steps_offset and the reference calls
         # set_timesteps(steps) without one => offset 0 is the pinned behaviour
-        self.config = _Config(num_train_timesteps=num_train_timesteps, beta_start=beta_start,
-                              beta_end=beta_end, beta_schedule=beta_schedule,
-                              clip_sample=clip_sample, set_alpha_to_one=set_alpha_to_one,
-                              steps_offset=steps_offset, prediction_type=prediction_type)
+        self._set_config(num_train_timesteps=num_train_timesteps, beta_start=beta_start,
+                         beta_end=beta_end, beta_schedule=beta_schedule,
+                         clip_sample=clip_sample, set_alpha_to_one=set_alpha_to_one,
+                         steps_offset=steps_offset, prediction_type=prediction_type)
         self.num_inference_steps: Optional[int] = None
         self.timesteps = np.arange(0, num_train_timesteps)[::-1].copy()
 
@@ -54,7 +78,7 @@ class DDIMScheduler():
     def set_timesteps(self, num_inference_steps: int, offset: Optional[int] = None):
         '''diffusers 0.3.0: arange(0, T, T // n)[::-1] + offset.'''
         T = self.config['num_train_timesteps']
-        off = self.config['steps_offset'] if offset is None else offset
+        off = self.config.get('steps_offset', 0) if offset is None else offset
         self.num_inference_steps = num_inference_steps
         self.timesteps = (np.arange(0, T, T // num_inference_steps)[::-1].copy().astype(np.int64)
                           + off)
@@ -98,7 +122,7 @@ class DDIMScheduler():
                          float(np.sqrt(a)), float(np.sqrt(np.float32(1.0) - a)))
 
 
-class PNDMScheduler():
+class PNDMScheduler(_Configured):
     '''PLMS branch (skip_prk_steps=True, what Stable Diffusion v1 ships and what the reference's
     `Runner` actually passes, utils.py:70) of diffusers 0.3.0's `PNDMScheduler`, restated
     from the published algorithm.  PARITY UNPINNED (diffusers is not installed); the linear
@@ -111,9 +135,9 @@ class PNDMScheduler():
         betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
                             dtype=np.float32) ** 2
         self.alphas_cumprod = np.cumprod(1.0 - betas, axis=0).astype(np.float32)
-        self.config = _Config(num_train_timesteps=num_train_timesteps, beta_start=beta_start,
-                              beta_end=beta_end, beta_schedule=beta_schedule,
-                              skip_prk_steps=skip_prk_steps, steps_offset=steps_offset)
+        self._set_config(num_train_timesteps=num_train_timesteps, beta_start=beta_start,
+                         beta_end=beta_end, beta_schedule=beta_schedule,
+                         skip_prk_steps=skip_prk_steps, steps_offset=steps_offset)
         self.timesteps = np.arange(0, num_train_timesteps)[::-1].copy()
         self.num_inference_steps = None
         self._offset = 0
@@ -124,7 +148,7 @@ class PNDMScheduler():
 
     def set_timesteps(self, num_inference_steps: int, offset: Optional[int] = None):
         T = self.config['num_train_timesteps']
-        self._offset = self.config['steps_offset'] if offset is None else offset
+        self._offset = self.config.get('steps_offset', 0) if offset is None else offset
         self.num_inference_steps = num_inference_steps
         base = np.arange(0, T, T // num_inference_steps) + self._offset
         # second timestep repeated: the first PLMS step is a two-evaluation (Heun-like) start
@@ -178,7 +202,7 @@ class PNDMScheduler():
                          float(np.sqrt(a)), float(np.sqrt(np.float32(1.0) - a)))
 
 
-class LMSDiscreteScheduler():
+class LMSDiscreteScheduler(_Configured):
     '''K-LMS (linear multistep, order 4) of diffusers 0.3.0, restated from the published
     algorithm.  PARITY UNPINNED.  The pipeline applies the sigma input scaling exactly where
     the reference does (pipeline/flex.py:236-238, 270-274).'''
@@ -191,8 +215,8 @@ class LMSDiscreteScheduler():
         self.alphas_cumprod = np.cumprod(1.0 - betas, axis=0).astype(np.float32)
         self.train_sigmas = ((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5
         self.sigmas = self.train_sigmas
-        self.config = _Config(num_train_timesteps=num_train_timesteps, beta_start=beta_start,
-                              beta_end=beta_end, beta_schedule=beta_schedule)
+        self._set_config(num_train_timesteps=num_train_timesteps, beta_start=beta_start,
+                         beta_end=beta_end, beta_schedule=beta_schedule)
         self.timesteps = np.arange(0, num_train_timesteps)[::-1].copy()
         self.num_inference_steps = None
         self.derivatives = []

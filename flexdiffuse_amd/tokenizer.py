@@ -123,6 +123,7 @@ class CLIPBPETokenizer():
         self._pieces = regex.compile(
             r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|\p{L}+|\p{N}|[^\s\p{L}\p{N}]+")
         self._space = regex.compile(r'\s+')
+        self._specials = regex.compile(r'(<\|startoftext\|>|<\|endoftext\|>)')
         self._memo: Dict[str, List[str]] = {}
 
     @classmethod
@@ -178,9 +179,9 @@ class CLIPBPETokenizer():
 
     @classmethod
     def _basic_clean(cls, text: str) -> str:
-        '''BasicTokenizer's two clean-ups (see the class docstring): drop NUL / U+FFFD / control
-        characters (category C*, except tab / newline / carriage return, which count as whitespace),
-        map whitespace to a space, and put spaces around CJK ideographs.'''
+        '''BasicTokenizer's character clean-ups: drop NUL / U+FFFD / control characters (category C*,
+        except tab / newline / carriage return, which count as whitespace), map whitespace to a space,
+        and put spaces around CJK ideographs.'''
         out = []
         for ch in text:
             cp = ord(ch)
@@ -194,10 +195,44 @@ class CLIPBPETokenizer():
                 out.append(ch)
         return ''.join(out)
 
+    @staticmethod
+    def _is_punctuation(ch: str) -> bool:
+        cp = ord(ch)
+        if 33 <= cp <= 47 or 58 <= cp <= 64 or 91 <= cp <= 96 or 123 <= cp <= 126:
+            return True                  # every non-alphanumeric ASCII symbol counts ("$", "^", "`" too)
+        return unicodedata.category(ch).startswith('P')
+
+    @classmethod
+    def _basic_tokens(cls, text: str) -> List[str]:
+        '''BERT BasicTokenizer(do_lower_case=True) as published: character clean-ups, whitespace split,
+        then per token lower case, accent stripping (NFD, combining marks dropped) and a split at EVERY
+        punctuation character.  "don't" -> don ' t;  "café" -> cafe.'''
+        out: List[str] = []
+        for tok in cls._basic_clean(text).split():
+            tok = ''.join(c for c in unicodedata.normalize('NFD', tok.lower())
+                          if unicodedata.category(c) != 'Mn')
+            word = ''
+            for c in tok:
+                if cls._is_punctuation(c):
+                    if word:
+                        out.append(word)
+                    out.append(c)
+                    word = ''
+                else:
+                    word += c
+            if word:
+                out.append(word)
+        return out
+
     def tokenize(self, text: str) -> List[str]:
         if self.text_cleanup == 'basic':
-            text = self._basic_clean(text)
-        text = self._space.sub(' ', unicodedata.normalize('NFC', text)).lower()
+            # the slow tokenizer cuts the registered special tokens out of the text first and hands only
+            # the stretches between them to BasicTokenizer; no NFC afterwards
+            parts = self._specials.split(text)
+            text = ' '.join(p if p in (self.BOS, self.EOS) else ' '.join(self._basic_tokens(p)) for p in parts)
+            text = self._space.sub(' ', text).strip()
+        else:
+            text = self._space.sub(' ', unicodedata.normalize('NFC', text)).lower()
         out: List[str] = []
         for piece in self._pieces.findall(text):
             if piece in (self.BOS, self.EOS):

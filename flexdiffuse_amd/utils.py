@@ -60,19 +60,46 @@ def entity_from_row(row: Sequence[Any]) -> Optional[EntitySchema]:
 
 
 class Runner():
-    def __init__(self, state_dicts: Optional[Dict[str, dict]] = None, preset: str = 'sd15',
-                 device: str = 'cuda', seed_weights: int = 0) -> None:
-        if state_dicts is None:
-            state_dicts = build.synthetic_state_dicts(preset, seed=seed_weights)
-        self.pipe, clip, tok = build.build_models(state_dicts, preset, device)
+    def __init__(self, local: bool = True, device: str = 'cuda', *, sd_dir: Optional[str] = None,
+                 clip_dir: Optional[str] = None, tokenizer_dir: Optional[str] = None,
+                 state_dicts: Optional[Dict[str, dict]] = None, preset: str = 'sd15', seed_weights: int = 0,
+                 freeze_gc: bool = False, pause_gc: bool = False) -> None:
+        '''`Runner(local=True, device='cuda')` as the reference constructs it (utils.py:54-76); the hub
+        ids the reference hard-codes (utils.py:24-25) become local directories:
+          sd_dir        diffusers-layout checkpoint (unet/, vae/, tokenizer/) -- env FD_SD_DIR
+          clip_dir      CLIPModel directory                                    -- env FD_CLIP_DIR
+          tokenizer_dir vocab.json + merges.txt; default `sd_dir`/tokenizer     -- env FD_TOKENIZER_DIR
+        `local=False` (the reference's --dl) cannot be served: there is no hub access here.
+        Without directories: `state_dicts` (fp32 CPU tensors with HF key names) or seeded synthetic
+        weights of `preset` with the synthetic tokenizer.
+        `freeze_gc` / `pause_gc` (both off by default: they change interpreter-global state): park the
+        long-lived model objects in the GC's permanent generation / keep the cyclic GC off across each
+        denoising loop -- what `bench.py` runs with.'''
+        if not local:
+            raise RuntimeError('Runner(local=False): no network access -- place the checkpoint on disk and pass '
+                               'sd_dir / clip_dir (or set FD_SD_DIR / FD_CLIP_DIR)')
+        sd_dir = sd_dir or os.environ.get('FD_SD_DIR')
+        clip_dir = clip_dir or os.environ.get('FD_CLIP_DIR')
+        tokenizer_dir = tokenizer_dir or os.environ.get('FD_TOKENIZER_DIR')
+        if sd_dir or clip_dir:
+            if not (sd_dir and clip_dir):
+                raise ValueError('Runner needs both sd_dir and clip_dir (utils.py:24-25: two checkpoints)')
+            self.pipe, clip, tok = build.from_directories(sd_dir, clip_dir, tokenizer_dir, preset=preset,
+                                                          device=device)
+        else:
+            if state_dicts is None:
+                state_dicts = build.synthetic_state_dicts(preset, seed=seed_weights)
+            tok = build.load_tokenizer(tokenizer_dir) if tokenizer_dir else None
+            self.pipe, clip, tok = build.build_models(state_dicts, preset, device, tokenizer=tok)
+        self.pipe.pause_gc = pause_gc
         self.device = device
-        self.encoder = CLIPEncoder(clip, tok)
-        self.guide = Guide(clip, tok, device=device)
+        self.encoder = CLIPEncoder(clip, self.pipe.tokenizer)     # utils.py:73-74
+        self.guide = Guide(clip, self.pipe.tokenizer, device=device)
         self.generator = torch.Generator(device='cpu')     # E6: host generator
         self.eta = 0.0                                      # E5: never overwritten
         # the models and tokenizer tables are millions of long-lived objects: a full collection over them is a 50-100 ms
-        # host stall between denoising loops (measured in bench.py's timed region); park them in the permanent generation
-        if os.environ.get('FD_GC_FREEZE', '1') != '0':
+        # host stall between denoising loops (measured in bench.py's timed region)
+        if freeze_gc:
             gc.collect()
             gc.freeze()
 

@@ -32,7 +32,7 @@ extern "C" {
 #define FD_ESHAPE (-2) /* unsupported shape / alignment */
 #define FD_EHIP (-3)   /* HIP runtime error */
 
-#define FD_ABI_VERSION 8
+#define FD_ABI_VERSION 9
 
 int fd_abi_version(void);
 const char* fd_last_error(void);
@@ -54,6 +54,10 @@ int fd_prof_set_stride(int stride);
  * (FLOPs for MFMA families, algorithmic bytes for HBM families) and launch count, and
  * forgets those records. Host pointers. */
 int fd_prof_collect(int family, double* total_ms, double* total_work, int64_t* launches);
+/* (ABI 9) the same plus `total_executed`: the work the kernels really issued -- equal to the declared work except
+ * where a launch implements an op with fewer MACs than its definition (parity-decomposed upsample convolution: 4/9).
+ * The hardware roofline is `executed` / time; `work` / time is the algorithmic-equivalent rate. */
+int fd_prof_collect2(int family, double* total_ms, double* total_work, double* total_executed, int64_t* launches);
 /* Mean elapsed ms of an EMPTY event bracket (`pairs` back-to-back record pairs on `stream`);
  * subtract it per sampled launch to turn bracket time into kernel time. Host pointer. */
 int fd_prof_calibrate(int pairs, double* ms_per_empty_pair, void* stream);
@@ -286,13 +290,15 @@ int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const float* gamma
                              void* stream);
 /* GroupNorm folded into the linear layer that consumes it (the transformer block's norm -> proj_in, diffusers
  * Transformer2DModel.norm / proj_in inside the `unet(...)` call of reference pipeline/guide.py:56-58):
- *   proj_in(GN(x))[m][n] = sum_c (W[n][c] gamma_c rstd_{b,g(c)}) x[m][c] + (bias[n] + (W beta)[n] - sum_g mean_{b,g} rstd_{b,g} S[n][g])
+ *   proj_in(GN(x))[m][n] = sum_c w_out[b][n][c] x[m][c] + (bias[n] + (W beta)[n] - sum_g mean_{b,g} sum_{c in g} w_out[b][n][c]),
+ *   w_out[b][n][c] = fp16(W[n][c] gamma_c rstd_{b,g(c)})
  * One statistics pass over x [B][HW][ldx] (the first launch of fd_groupnorm_nhwc_ld_f16), then per sample b the scaled
- * weights w_out [B][N][C] fp16 and bias_out [B][N] fp32 from the model constants wg = W diag(gamma) (fp16 [N][C]),
- * S[n][g] = sum_{c in g} wg[n][c] (fp32 [N][G]) and biasf = bias + W beta (fp32 [N]).  The normalised activation is never
- * written: the consumer is fd_gemm_f16 with batch = B, batch_stride_w = N * C, batch_stride_bias = N on x itself. */
+ * weights w_out [B][N][C] fp16 and bias_out [B][N] fp32 from the model constants wg = W diag(gamma) (fp16 [N][C]) and
+ * biasf = bias + W beta (fp32 [N]).  (ABI 9) the mean term is summed over the ROUNDED w_out, so a group mean cancels
+ * exactly whatever its size relative to the group's spread.  The normalised activation is never written: the consumer is
+ * fd_gemm_f16 with batch = B, batch_stride_w = N * C, batch_stride_bias = N on x itself. */
 int fd_groupnorm_fold_linear_f16(const void* x, int ldx, float* ws, int B, int HW, int C, int G, float eps,
-                                 const void* wg, const float* S, const float* biasf, int N,
+                                 const void* wg, const float* biasf, int N,
                                  void* w_out, float* bias_out, void* stream);
 /* LayerNorm over the last dim of fp16 x [rows][ldx] -> fp16 (or fp32) y [rows][ldy]. */
 int fd_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int rows,

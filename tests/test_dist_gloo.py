@@ -106,6 +106,63 @@ def test_sharded_hot_path_equals_single_process(tmp_path):
     assert float((lat[0] - lat[2]).abs().max()) > 1e-3      # the prompts / noise differ per sample
 
 
+def _img2img_shard(prompts, posterior, noise, steps=4, strength=0.5):
+    '''img2img rank-local stage on the mini CPU oracle: encode -> posterior sample -> add_noise with the
+    rank's rows -> loop from t_start -> decode (reference pipeline/flex.py:181-221, 262-287).'''
+    from flexdiffuse_amd import build
+    from flexdiffuse_amd.tokenizer import SyntheticTokenizer
+    from oracle import clip_ref, pipeline_ref
+    torch.set_num_threads(2)
+    sds = build.synthetic_state_dicts('mini', seed=0)
+    ucfg, vcfg, ccfg = build.configs('mini')
+    tok = SyntheticTokenizer(vocab_size=ccfg.text.vocab_size)
+    embeds = clip_ref.text_hidden(sds['clip'], ccfg, tok(list(prompts)).input_ids)
+    uncond = clip_ref.text_hidden(sds['clip'], ccfg, tok('').input_ids)
+    image = torch.linspace(-1, 1, 3 * 16 * 16).view(1, 3, 16, 16)
+    lat0, t_start = pipeline_ref.img2img_init(sds['vae'], vcfg, image, posterior, noise, steps, strength,
+                                              noise.shape[0])
+    lat, _ = pipeline_ref.denoise(sds['unet'], ucfg, embeds, uncond, lat0, steps, 8.0, t_start=t_start)
+    return lat, pipeline_ref.decode_image(sds['vae'], vcfg, lat)
+
+
+def _worker_img2img(rank, world, port, per_rank, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from flexdiffuse_amd import dist as fdist
+    fdist.init('gloo')
+    post, noise = fdist.global_img2img_noise(world * per_rank, (4, 8, 8), seed=1337)
+    lat, img = _img2img_shard(fdist.shard(PROMPTS, rank, world, per_rank), post,
+                              noise[fdist.shard_range(rank, world, per_rank)])
+    all_lat, all_img = fdist.all_gather_samples(lat), fdist.all_gather_samples(img)
+    if rank == 0:
+        torch.save((all_lat, all_img), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_img2img_equals_single_process(tmp_path):
+    '''The img2img branch (BASELINE configs[3]) is shard-invariant too: the posterior sample is the first
+    draw of the one host generator (shared by all samples, as the reference repeats the encoded latent),
+    the add_noise rows are slices of the second -- `dist.global_img2img_noise`, what bench.py --img2img and
+    `FlexPipeline.__call__(noise=...)` use.'''
+    from flexdiffuse_amd import dist as fdist
+    world, per_rank = 2, 2
+    out = str(tmp_path / 'i2i.pt')
+    mp.spawn(_worker_img2img, args=(world, _free_port(), per_rank, out), nprocs=world, join=True)
+    all_lat, all_img = torch.load(out)
+    post, noise = fdist.global_img2img_noise(world * per_rank, (4, 8, 8), seed=1337)
+    lat, img = _img2img_shard(PROMPTS, post, noise)
+    assert all_lat.shape == lat.shape == (4, 4, 8, 8)
+    assert float((all_lat - lat).abs().max()) <= 1e-4 * float(lat.abs().max())
+    assert float((all_img - img).abs().max()) <= 1e-4
+    assert float((lat[0] - lat[3]).abs().max()) > 1e-3
+    # and the draws are the pipeline's: one generator, posterior first
+    g = torch.Generator('cpu').manual_seed(1337)
+    assert torch.equal(post, torch.randn((1, 4, 8, 8), generator=g))
+    assert torch.equal(noise, torch.randn((4, 4, 8, 8), generator=g))
+
+
 def test_single_process_is_identity():
     from flexdiffuse_amd import dist as fdist
     x = torch.arange(12.0).view(3, 4)

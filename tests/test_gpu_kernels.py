@@ -662,6 +662,32 @@ def test_groupnorm_folded_into_proj_in(dev, B, H, C, N, ld):
     assert float((plain.float() - got.float()).abs().max()) <= 2e-3 * scale
 
 
+def test_groupnorm_fold_with_large_group_means(dev):
+    '''Real UNet residual streams carry group means several times their spread.  The fold subtracts the mean through
+    the bias, so it only cancels if that bias is summed over the SAME rounded fp16 weights the GEMM multiplies with
+    (ABI 9); with means of 10 sigma the error must stay in the class of the unfused path, not grow 10x.'''
+    from flexdiffuse_amd import ops
+    B, H, C, N, G = 4, 32, 320, 320, 32
+    HW = H * H
+    g = torch.Generator().manual_seed(77)
+    means = torch.randn((B, 1, G), generator=g).repeat_interleave(C // G, dim=2) * 10.0
+    x32 = (torch.randn((B, HW, C), generator=g) + means).half().float()
+    w = torch.randn((N, C), generator=g) * C ** -0.5
+    b = torch.randn(N, generator=g) * 0.3
+    gamma, beta = 1.0 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    want = F.linear(F.group_norm(x32.permute(0, 2, 1), G, gamma, beta, 1e-6).permute(0, 2, 1), w, b).reshape(B * HW, N)
+    xa = ops.Act(x32.reshape(B * HW, C).half().to(dev), B, H, H)
+    gf = ops.prep_gn_fold(w, b, gamma, beta, G, 1e-6, dev)
+    wb, bb = ops.gn_fold_linear(xa, gf)
+    got = ops.gemm_per_sample(xa.t, wb, bb, B, HW)
+    unf = ops.gemm(ops.groupnorm(xa, ops.f32(gamma, dev), ops.f32(beta, dev), G, 1e-6, False).t, ops.prep_linear(w, b, dev))
+    e_fold, e_unf = (got.float().cpu() - want).abs(), (unf.float().cpu() - want).abs()
+    print(f'GN fold at |mean| = 10 sigma: mean err {float(e_fold.mean()):.2e} (unfused {float(e_unf.mean()):.2e}), '
+          f'max {float(e_fold.max()):.2e} (unfused {float(e_unf.max()):.2e})')
+    assert float(e_fold.mean()) <= 2.0 * float(e_unf.mean()) + 1e-6
+    assert float(e_fold.max()) <= 3.0 * float(e_unf.max()) + 1e-6
+
+
 def test_per_batch_bias_is_refused_where_it_cannot_be_staged(dev):
     from flexdiffuse_amd import ops
     a = torch.zeros((512, 64), dtype=torch.float16, device=dev)

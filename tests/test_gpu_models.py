@@ -466,11 +466,38 @@ def _cached_oracle_psnr(name, dev, pipe, clip, tok, sds, vcfg):
           f'PSNR {p:.1f} dB, image std {float(img_ref.std()):.3f}, {len(want_t)} UNet evaluations')
     assert out.images.shape == (1, c['size'], c['size'], 3)
     assert float(img_ref.std()) > 0.02, 'degenerate image: parity would be vacuous'
-    return p
+    # the config's REAL per-GPU batch (c4: 4, c5: 8 -- other tile / split-K choices, the 288-row tiles and the
+    # shared CFG prefix than batch 1): sample 0 of bench.py's batch against the same cached oracle latents
+    import bench
+    from flexdiffuse_amd import dist as fdist
+    nb, h = c['batch'], c['size'] // 8
+    prompts = bench.synth_prompts(nb)
+    assert prompts[0] == inp['prompt']
+    emb_b = Guide(clip, tok, device='cuda').embeds(prompt=prompts, guide=inp['guide'], **c['embeds_kw'])
+    guide_b = SimpleGuide(enc, pipe.unet, c['guidance'], c['steps'], emb_b)
+    if c['strength'] is not None:
+        post, noise_b = fdist.global_img2img_noise(nb, (4, h, h), c['gen_seed'])
+        # batch 1 drew (1,4,h,h) twice from the same generator: the posterior sample is shared, and sample 0's
+        # add_noise row is given the batch-1 draw so that the cached oracle applies
+        noise_b = torch.cat([inp['noise'], noise_b[1:]])
+        assert torch.equal(post, inp['posterior_noise'])
+        pipe(guide=guide_b, init_image=inp['init'], strength=c['strength'], noise=noise_b,
+             generator=torch.Generator('cpu').manual_seed(c['gen_seed']), output_type='np')
+    else:
+        noise_b = fdist.global_noise(nb, (4, h, h), c['noise_seed'])
+        assert torch.equal(noise_b[:1], inp['lat0'])
+        pipe(guide=guide_b, init_size=(c['size'], c['size']), latents=noise_b, output_type='np')
+    assert pipe.last_images.shape[0] == nb
+    pb = pipeline_ref.psnr(pipe.last_images[:1].cpu(), img_ref)
+    spread = float((pipe.last_images[0] - pipe.last_images[1]).abs().mean())
+    print(f'{name} at batch {nb}, sample 0: latent rel err {relerr(pipe.last_latents[:1], lat_ref):.4f}, '
+          f'PSNR {pb:.1f} dB; sample 0 vs 1 mean abs difference {spread:.3f}')
+    assert spread > 1e-3, 'all samples of the batch are the same image'
+    return min(p, pb)
 
 
 def test_sd15_c4_img2img_psnr(dev):
-    '''BASELINE configs[3] at batch 1: SD1.5 img2img + Linear image guidance, 768x768, 50 DDIM steps, strength
+    '''BASELINE configs[3] at batch 1 and at its per-GPU batch 4 (sample 0): SD1.5 img2img + Linear image guidance, 768x768, 50 DDIM steps, strength
     0.6 => the 30 evaluations of timesteps[20:] (reference pipeline/flex.py:181-221 init, :262-287 loop): VAE
     encode -> posterior sample -> add_noise -> loop -> decode on the device vs the cached CPU oracle;
     final-image PSNR >= 40 dB.'''
@@ -484,7 +511,7 @@ def test_sd15_c4_img2img_psnr(dev):
 
 
 def test_sd21_c5_psnr(dev):
-    '''BASELINE configs[4] at batch 1: SD2.1-size UNet (v-prediction, head dim 64, linear projections, context
+    '''BASELINE configs[4] at batch 1 and at its per-GPU batch 8 (sample 0): SD2.1-size UNet (v-prediction, head dim 64, linear projections, context
     1024) + OpenCLIP ViT-H/14 guide, 768x768, 50 DDIM steps, CFG 8, Linear image guidance, vs the cached CPU
     oracle (no reference behaviour exists for c5: the oracle is the target); final-image PSNR >= 40 dB.'''
     if not os.path.exists(os.path.join(GOLDEN, 'c5_oracle.npz')):
@@ -614,6 +641,72 @@ def test_runner_gen_vs_oracle(dev):
         assert p >= 40.0, (k, p)
     assert float((torch.from_numpy(np.asarray(imgs[0]).astype(np.float32)) -
                   torch.from_numpy(np.asarray(imgs[1]).astype(np.float32))).abs().mean()) > 0.5   # different noise per batch
+
+
+def test_runner_from_checkpoint_directories_vs_oracle(dev, tmp_path):
+    '''SURVEY 8(f) rank 4, end to end on the device: files on disk -> `Runner(local=True, device=...)` built the
+    way the reference builds it (utils.py:54-76: CLIPModel + StableDiffusionPipeline checkpoints -> models AND the
+    real tokenizer; the hub ids become local directories) -> `gen` -> images, against the oracle fed from the same
+    files through independent readers (safetensors.torch.load_file; transformers.CLIPTokenizer on the same
+    vocab.json / merges.txt as the third-party tokenizer oracle).  PSNR >= 40 dB per image.'''
+    import json
+    from safetensors.torch import load_file, save_file
+    from flexdiffuse_amd import FlexPipeline, Runner, build
+    from flexdiffuse_amd.tokenizer import CLIPBPETokenizer
+    from oracle import guide_ref, pipeline_ref
+    from test_oracle_clip import synth_image
+    from test_tokenizer import toy_vocab
+    preset = 'mini_bpe'
+    sds = build.synthetic_state_dicts(preset, seed=5)
+    sds = {k: {n: t.half().float() for n, t in sd.items()} for k, sd in sds.items()}
+    sd_dir, clip_dir = tmp_path / 'stable-diffusion', tmp_path / 'clip'
+    for sub in ('unet', 'vae', 'tokenizer'):
+        os.makedirs(sd_dir / sub)
+    os.makedirs(clip_dir)
+    save_file({k: v.contiguous() for k, v in sds['unet'].items()}, str(sd_dir / 'unet' / 'diffusion_pytorch_model.safetensors'))
+    save_file({k: v.contiguous() for k, v in sds['vae'].items()}, str(sd_dir / 'vae' / 'diffusion_pytorch_model.safetensors'))
+    save_file({k: v.contiguous() for k, v in sds['clip'].items()}, str(clip_dir / 'model.safetensors'))
+    vocab, merges = toy_vocab()
+    ucfg, vcfg, ccfg = build.configs(preset)
+    assert len(vocab) <= ccfg.text.vocab_size
+    (sd_dir / 'tokenizer' / 'vocab.json').write_text(json.dumps(vocab), encoding='utf-8')
+    (sd_dir / 'tokenizer' / 'merges.txt').write_text('#version: 0.2\n' + '\n'.join(' '.join(m) for m in merges) + '\n',
+                                                     encoding='utf-8')
+    with pytest.raises(RuntimeError):
+        Runner(local=False, device='cuda', sd_dir=str(sd_dir), clip_dir=str(clip_dir), preset=preset)
+    with pytest.raises(ValueError):
+        Runner(local=True, device='cuda', sd_dir=str(sd_dir), preset=preset)
+    r = Runner(True, 'cuda', sd_dir=str(sd_dir), clip_dir=str(clip_dir), preset=preset)
+    assert isinstance(r.pipe.tokenizer, CLIPBPETokenizer) and r.encoder.tokenizer is r.pipe.tokenizer
+    assert isinstance(FlexPipeline.from_pretrained(str(sd_dir), str(clip_dir), preset=preset), FlexPipeline)
+    prompt = "a photo of the painter's dog, highly detailed oil painting of mountains at sunset"
+    img = synth_image(21, 512, 512)
+    steps, samples, seed, hw = 4, 2, 77, 64
+    kw = dict(guide_clustered=0.0, guide_threshold_mult=0.25, guide_linear=(0.0, 0.5))
+    imgs, _ = r.gen(prompt=prompt, guide=img, init_size=(hw, hw), steps=steps, samples=samples, seed=seed,
+                    guidance_scale=8, **kw)
+    # ---- the oracle, from the same files through other readers
+    ref_sds = {'unet': load_file(str(sd_dir / 'unet' / 'diffusion_pytorch_model.safetensors')),
+               'vae': load_file(str(sd_dir / 'vae' / 'diffusion_pytorch_model.safetensors')),
+               'clip': load_file(str(clip_dir / 'model.safetensors'))}
+    transformers = pytest.importorskip('transformers')
+    try:
+        ref_tok = transformers.CLIPTokenizer(vocab=vocab, merges=merges, model_max_length=77)
+    except Exception:
+        ref_tok = transformers.CLIPTokenizer(vocab=vocab, merges=[' '.join(m) for m in merges], model_max_length=77)
+    ids_ref = ref_tok(prompt, padding='max_length', max_length=77, truncation=True, return_tensors='pt').input_ids
+    assert torch.equal(r.pipe.tokenizer(prompt).input_ids, ids_ref) and int((ids_ref != ref_tok.eos_token_id).sum()) > 10
+    g = guide_ref.GuideRef(ref_sds['clip'], ccfg, ref_tok)
+    embeds = g.embeds(prompt=prompt, guide=img, guide_mode=0, **kw)
+    gen = torch.Generator('cpu').manual_seed(seed)
+    for k in range(samples):
+        lat0 = torch.randn((1, 4, hw // 8, hw // 8), generator=gen)
+        lat, _ = pipeline_ref.denoise(ref_sds['unet'], ucfg, embeds, g.prompt(''), lat0, steps, 8.0)
+        want = (pipeline_ref.decode_image(ref_sds['vae'], vcfg, lat) * 255).round() / 255
+        got = torch.from_numpy(np.asarray(imgs[k]).astype(np.float32) / 255).permute(2, 0, 1)[None]
+        p = pipeline_ref.psnr(got, want)
+        print(f'Runner from checkpoint directories, sample {k}: PSNR {p:.1f} dB vs the oracle')
+        assert p >= 40.0, (k, p)
 
 
 def test_ddim_eta_step_and_loop_vs_oracle(mini, dev):

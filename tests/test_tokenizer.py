@@ -120,8 +120,8 @@ def test_from_pretrained_layout(tmp_path):
 def test_basic_cleanup_mode_known_answers():
     '''text_cleanup='basic': the slow CLIPTokenizer's no-ftfy path (BERT BasicTokenizer first) that the
     reference's pinned transformers 4.21.1 runs -- control / NUL / U+FFFD characters dropped, every CJK
-    ideograph its own piece -- against known answers of the published algorithm; identical to the default
-    mode on prompts without such characters.'''
+    ideograph its own piece -- against known answers of the published algorithm; accents stripped, every
+    punctuation character its own piece; identical to the default mode on plain alphanumeric prompts.'''
     vocab, merges = toy_vocab()
     fast, basic = CLIPBPETokenizer(vocab, merges), CLIPBPETokenizer(vocab, merges, text_cleanup='basic')
     assert CLIPBPETokenizer._basic_clean('a\x00b\x07c\ufffdd') == 'abcd'
@@ -133,9 +133,20 @@ def test_basic_cleanup_mode_known_answers():
     assert basic.tokenize('日本語') == [t for ch in '日本語' for t in fast.tokenize(ch)]
     assert fast.tokenize('日本語') != basic.tokenize('日本語')
     assert basic.encode('a\x00b') == fast.encode('ab') != fast.encode('a\x00b')
-    for p in PROMPTS:
-        if all(not CLIPBPETokenizer._is_cjk(ord(c)) and (c in '\t\n\r' or not __import__('unicodedata').category(c).startswith('C'))
-               and c != '\ufffd' for c in p):
+    # BasicTokenizer(do_lower_case=True) also strips accents and splits at every punctuation character
+    assert CLIPBPETokenizer._basic_tokens("Don't stop") == ['don', "'", 't', 'stop']
+    assert CLIPBPETokenizer._basic_tokens('Café naïve, über!') == ['cafe', 'naive', ',', 'uber', '!']
+    assert CLIPBPETokenizer._basic_tokens('wait... what?!') == ['wait', '.', '.', '.', 'what', '?', '!']
+    assert CLIPBPETokenizer._basic_tokens('a$b^c`d') == ['a', '$', 'b', '^', 'c', '`', 'd']
+    assert basic.encode("it's") == fast.encode('it') + fast.encode("'") + fast.encode('s') != fast.encode("it's")
+    assert basic.encode('café') == fast.encode('cafe') != fast.encode('café')
+    assert basic.encode('mountains... at') == fast.encode('mountains') + 3 * fast.encode('.') + fast.encode('at')
+    # registered special tokens are cut out before BasicTokenizer sees the text
+    assert basic.encode('photo<|endoftext|>graph') == fast.encode('photo<|endoftext|>graph')
+    import unicodedata
+    plain = lambda p: all(c == ' ' or (c.isascii() and c.isalnum()) for c in p)
+    for p in PROMPTS + ['a photo of a cat sitting on the table', 'oil painting of 42 mountains']:
+        if plain(p):
             assert basic.encode(p) == fast.encode(p), p
     with pytest.raises(ValueError):
         CLIPBPETokenizer(vocab, merges, text_cleanup='ftfy')
