@@ -933,7 +933,7 @@ extern "C" int fd_attention_f16(const fd_attention_desc* d, void* stream) {
         else hipLaunchKernelGGL((k_attention_w8<DQK, DV, false, ONES>), grid, dim3(512), 0, st, a);    \
     }
     // also on the short text-context rows (n_k = 77): K / V^T staging per query halves (38.6 -> 36.9 us at 16x4096 queries)
-    static const int q2_mink = getenv("FD_ATTN_Q2_MINK") ? atoi(getenv("FD_ATTN_Q2_MINK")) : 64;
+    const int q2_mink = 64;
     if (hd <= 48 && wide == 2 && q2 && d->n_q >= 2048 && d->n_k >= q2_mink) {
         dim3 grid2(fd_cdiv(d->n_q, 256) * d->heads * d->batch);
         if (hd <= 40) {

@@ -1440,7 +1440,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs g) {
 
 // --------------------------------------------------------------------------------------
 static bool g_use_dma = getenv("FD_GEMM_NO_DMA") == nullptr;
-static int g_vae15 = getenv("FD_GEMM_VAE15") ? atoi(getenv("FD_GEMM_VAE15")) : 1;
+static const int g_vae15 = 1;   // 256x256 tiles on the VAE widths (A/B closed in round 1: +19..33 %)
 static int g_tap_fast = getenv("FD_CONV_TAPFAST") ? atoi(getenv("FD_CONV_TAPFAST")) : 1;   // 1: 256x320 tile, 2: every conv tile
 static int g_bias_lds = getenv("FD_GEMM_BIAS_LDS") ? atoi(getenv("FD_GEMM_BIAS_LDS")) : 1;
 static int g_fast_epi = getenv("FD_GEMM_FAST_EPI") ? atoi(getenv("FD_GEMM_FAST_EPI")) : 1;   // 0: generic epilogue only (A/B)
@@ -1486,15 +1486,10 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
                                    st, g, (unsigned)a_bytes, (unsigned)w_bytes);
             }
         } else {
-            // measured neutral (profiles/r03_session_ab.txt sec. 5): off by default, kept as an A/B knob
-            static const int sk_flat = getenv("FD_GEMM_SK_FLAT") ? atoi(getenv("FD_GEMM_SK_FLAT")) : 0;
-            if (g.split_k > 1 && batch == 1 && sk_flat) {
-                g.sk_flat = 1;
-                grid = dim3(g.tiles_m * g.tiles_n * g.split_k, 1, 1);
-            }
+            // (a flat split-K grid with one K slice per XCD -- GemmArgs.sk_flat -- measured neutral, profiles/r03_session_ab.txt
+            // sec. 5: the A/B is closed and its switch removed; the kernel keeps the index path for the record)
             hipLaunchKernelGGL((k_gemm_f16_dma<BM, BN, CONV, WM, TRANS, NS, WN, EPI>), grid, dim3(64 * WM * WN), lds, st, g,
                                (unsigned)a_bytes, (unsigned)w_bytes);
-            g.sk_flat = 0;
         }
         FD_CHECK_LAUNCH("k_gemm_f16_dma");
         return FD_OK;
@@ -1584,7 +1579,7 @@ static int launch_epi(GemmArgs& g, int batch, hipStream_t st) {
 // epilogue and LDS-staged biases (FD_GEMM_FAST_EPI / FD_GEMM_BIAS_LDS / FD_GEMM_NO_DMA are A/B switches that
 // take those away).  Callers that get 0 run fd_ln_row_stats_f16 on the output instead.
 // fraction of the CU slots busy over the launch's rounds (slots = 256 CUs x workgroups per CU)
-static int g_t23 = getenv("FD_GEMM_T23") ? atoi(getenv("FD_GEMM_T23")) : 1;   // 0: never pick the 288x160 tile by rule (A/B)
+static const int g_t23 = 1;   // the 288x160 tile for row counts 9 * 2^k (A/B closed in round 3: c4 / c5 +16..18 %)
 static double fd_round_eff(long long tiles, int slots) {
     return (double)tiles / (double)((long long)slots * ((tiles + slots - 1) / slots));
 }

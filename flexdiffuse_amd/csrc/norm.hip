@@ -511,13 +511,11 @@ extern "C" int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const f
     hipStream_t st = (hipStream_t)stream;
     const int c8 = C / 8;
     FD_CHECK_ARG(c8 <= 1024, FD_ESHAPE, "fd_groupnorm_nhwc_f16: C=%d too large", C);
-    // slabs that fit a workgroup's registers: one launch, one read (FD_GN_NO_SMALL=1: never,
-    // =2: only the 256-thread form)
+    // slabs that fit a workgroup's registers: one launch, one read
     {
-        const char* e = getenv("FD_GN_NO_SMALL");
-        const int off = e ? atoi(e) : 0;
+        const int off = 0;
         int rc = FD_OK;
-        if (off != 1 && gn_try_slab<256, 16>(x, y, gamma, beta, B, HW, C, G, eps, silu, st, &rc, ldx)) return rc;
+        if (gn_try_slab<256, 16>(x, y, gamma, beta, B, HW, C, G, eps, silu, st, &rc, ldx)) return rc;
         // 1024-thread slabs pay off up to 32x32 maps; at 64x64 the 80-byte rows of a narrow slab
         // waste cache lines and the two streaming passes below are as fast or faster (measured)
         if (off == 0 && HW <= 1024 && gn_try_slab<1024, 22>(x, y, gamma, beta, B, HW, C, G, eps, silu, st, &rc, ldx)) return rc;

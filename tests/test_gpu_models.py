@@ -677,7 +677,7 @@ def test_runner_from_checkpoint_directories_vs_oracle(dev, tmp_path):
     with pytest.raises(ValueError):
         Runner(local=True, device='cuda', sd_dir=str(sd_dir), preset=preset)
     r = Runner(True, 'cuda', sd_dir=str(sd_dir), clip_dir=str(clip_dir), preset=preset)
-    assert isinstance(r.pipe.tokenizer, CLIPBPETokenizer) and r.encoder.tokenizer is r.pipe.tokenizer
+    assert isinstance(r.pipe.tokenizer, CLIPBPETokenizer) and r.encoder.token is r.pipe.tokenizer
     assert isinstance(FlexPipeline.from_pretrained(str(sd_dir), str(clip_dir), preset=preset), FlexPipeline)
     prompt = "a photo of the painter's dog, highly detailed oil painting of mountains at sunset"
     img = synth_image(21, 512, 512)
