@@ -346,7 +346,7 @@ def plumbing_rank(args) -> None:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=8, help='images per GPU')
     ap.add_argument('--ddim-steps', type=int, default=50)
@@ -355,11 +355,13 @@ def main():
     ap.add_argument('--guidance', default='linear', choices=sorted(GUIDANCE))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
-    ap.add_argument('--graph', action='store_true', help='replay the UNet from a captured HIP graph')
-    ap.add_argument('--launch', default='plan', choices=['plan', 'eager'],
-                    help='plan (default): the UNet forward is replayed from its recorded launch plan '
-                         '(same kernels, same order, eager launches, no per-op host work); eager: every '
-                         'op goes through the Python front each step')
+    ap.add_argument('--graph', action='store_true', help='same as --launch graph')
+    ap.add_argument('--launch', default='graph', choices=['graph', 'plan', 'eager'],
+                    help='graph (default): the UNet forward is replayed from a captured HIP graph -- one host call per '
+                         'denoising step, so a host stall (shared hosts of the GPU pool: one 30 ms stall in four passes seen in '
+                         'plan mode) cannot starve the device; same kernels and, since round 4, the same device time as plan '
+                         '(profiles/r04_session_ab.txt); plan: the recorded launch plan (same kernels, same order, eager '
+                         'launches, no per-op host work); eager: every op goes through the Python front each step')
     ap.add_argument('--img2img', action='store_true',
                     help='BASELINE configs[3] (c4): start from a synthetic init image of --size, '
                          '--strength 0.6 => int(steps * strength) UNet evaluations (pipeline/flex.py:181-221)')
@@ -412,7 +414,7 @@ def main():
     if args.scheduler != 'ddim':
         from flexdiffuse_amd.scheduler import LMSDiscreteScheduler, PNDMScheduler
         pipe.scheduler = PNDMScheduler() if args.scheduler == 'pndm' else LMSDiscreteScheduler()
-    pipe.use_graph = args.graph
+    pipe.use_graph = args.graph or args.launch == 'graph'
     pipe.pause_gc = True          # with the gc.freeze() below: no collector pauses inside the timed loops
     pipe.use_plan = args.launch == 'plan' and not args.graph
     guide_ctx = Guide(clip, tok, device='cuda')
@@ -472,7 +474,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    launch_note = None
     for w in range(args.warmup):
+        if w == 0 and pipe.use_graph:
+            # graph capture happens in the first pass: if it fails on this box, run on the launch plan instead of dying
+            try:
+                one_pass()
+                torch.cuda.synchronize()
+            except Exception as ex:      # noqa: BLE001
+                launch_note = f'HIP-graph capture failed ({type(ex).__name__}: {str(ex)[:200]}); ran on the launch plan'
+                pipe.use_graph, pipe.use_plan, pipe._graphs = False, True, {}
+                torch.cuda.synchronize()
+                one_pass()
+            continue
         one_pass()
     # The heap now holds the models, the tokenizer tables and the recorded launch plans (millions of long-lived
     # objects): a full collection over it is a 50-100 ms host stall, and the collector would schedule one whenever a
@@ -591,7 +605,7 @@ def main():
                        'images_per_step': B * N, 'parallelism': f'seed-sharded x{N}',
                        'preset': args.preset, 'guidance': args.guidance, 'img2img': args.img2img,
                        'unet_evaluations_per_image': ddim_evals, 'launch': margin['launch'],
-                       'scheduler': args.scheduler},
+                       'scheduler': args.scheduler, 'launch_note': launch_note},
             # ranks that took part in an RCCL (torch.distributed "nccl") process group; 0 for any
             # other backend (gloo plumbing runs) and for an undistributed N=1 run
             'rccl_ranks': dist.get_world_size() if dist.is_initialized() and dist.get_backend() == 'nccl' else 0,

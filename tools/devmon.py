@@ -2,7 +2,7 @@
 
 Boxes of the gpurun pool differ by a few percent on identical binaries (the MFMA loops are
 power-capped); this makes the difference a number.  Samples (time.time(), gfx clock MHz, socket
-power W, [mem clock MHz]) every --period seconds until stdin closes, then prints one JSON object
+power W, [mem clock MHz]) every --period seconds (default 0.1) until stdin closes, then prints one JSON object
 {"source": ..., "samples": [[t, sclk, power, mclk], ...]}.  bench.py starts it before its first GPU
 call and averages the samples that fall inside the timed region.
 
@@ -103,7 +103,7 @@ def open_source(index=0):
 
 def main():
     index = int(os.environ.get('FD_DEVMON_INDEX', '0'))
-    period = 0.05
+    period = 0.1
     if '--period' in sys.argv:
         period = float(sys.argv[sys.argv.index('--period') + 1])
     src, errs = open_source(index)
