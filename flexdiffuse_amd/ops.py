@@ -393,7 +393,9 @@ def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), 
     d.ld_bias2, d.rows_per_sample = ld_bias2, Ho * Wo
     d.act, d.out_f32, d.alpha, d.batch = act, int(out_f32), 1.0, 1
     if w.im2col:
-        assert not up
+        if up:
+            raise ValueError(f'conv2d: the fused nearest-2x upsample needs Cin % 64 == 0 (got {w.cin}): the explicit-im2col '
+                             'path of narrow inputs has no upsample form')
         cols = _empty((M, w.kpad), torch.float16, x.t)
         hip.call('fd_im2col_f16', x.t.data_ptr(), cols.data_ptr(), x.B, x.H, x.W, w.cin, Ho, Wo,
                  w.kh, w.kw, stride, pad[0], pad[1], w.kpad, hip.stream())

@@ -50,6 +50,65 @@ def test_gemm_linear(dev, M, N, K):
     close(out[:, :N], y * torch.sigmoid(1.702 * y), rtol=1e-3, atol=1e-3)
 
 
+def test_gemm_rule_cascade_on_shapes_outside_the_presets(dev):
+    '''fd_gemm_f16's tile / split-K rules were fitted to the GEMM shapes of four model presets; every OTHER shape must
+    still come out right (or be refused with FD_ESHAPE, never silently wrong).  48 seeded random (M, N, K) -- odd row
+    counts, N not a multiple of any tile, K with a tail, tiny and skinny problems, rows of 9 x 2^k -- through the
+    library's own choice (tile = split_k = 0), with bias, with and without a residual / activation, against fp32 torch;
+    plus 16 random convolutions (odd maps, stride 1 / 2, fused nearest-2x upsample, channel counts outside the UNet's).'''
+    from flexdiffuse_amd import ops
+    rng = np.random.default_rng(20240)
+    picks_m = [1, 3, 17, 64, 77, 130, 255, 256, 257, 1000, 1152, 2304, 4097, 9216, 20000]
+    picks_n = [8, 20, 36, 64, 96, 160, 200, 320, 328, 480, 640, 1000, 1280, 2048]
+    picks_k = [8, 24, 64, 72, 128, 200, 320, 520, 768, 1024, 1280, 2560, 4104]
+    refused = 0
+    for case in range(48):
+        M, N, K = int(rng.choice(picks_m)), int(rng.choice(picks_n)), int(rng.choice(picks_k))
+        a, w, b = rnd((M, K), 100 + case), rnd((N, K), 200 + case, K ** -0.5), rnd((N,), 300 + case)
+        lw = ops.prep_linear(w, b, dev)
+        ad = a.half().to(dev)
+        if lw.K != K:
+            ad = F.pad(ad, (0, lw.K - K))
+        mode = case % 3
+        try:
+            if mode == 0:
+                out = ops.gemm(ad, lw)
+                want = a @ w.T + b
+            elif mode == 1:
+                res = rnd((M, N), 400 + case)
+                out = ops.gemm(ad, lw, residual=F.pad(res, (0, (-N) % 4)).half().to(dev))
+                want = a @ w.T + b + res
+            else:
+                out = ops.gemm(ad, lw, act=ops.ACT_SILU)
+                want = F.silu(a @ w.T + b)
+        except ValueError as ex:      # FD_EINVAL / FD_ESHAPE: a loud refusal is allowed, a wrong result is not
+            print('refused', (M, N, K, mode), str(ex)[:120])
+            refused += 1
+            continue
+        got = out[:, :N].float().cpu()
+        err = (got - want).abs()
+        assert bool((err <= 3e-3 + 3e-3 * want.abs()).all()), ('linear', M, N, K, mode, float(err.max()))
+    assert refused <= 4, f'{refused} of 48 linear shapes refused'
+    for case in range(16):
+        B = int(rng.choice([1, 2, 3, 5]))
+        cin, cout = int(rng.choice([64, 96, 128, 192, 320, 448, 640])), int(rng.choice([32, 64, 100, 128, 320, 384]))
+        H, W = int(rng.choice([5, 8, 13, 16, 24, 33])), int(rng.choice([6, 8, 16, 20, 31]))
+        stride, up = (2, False) if case % 4 == 1 else (1, case % 4 == 2)
+        x, w, b = rnd((B, cin, H, W), 500 + case), rnd((cout, cin, 3, 3), 600 + case, (9 * cin) ** -0.5), rnd((cout,), 700 + case)
+        cw = ops.prep_conv(w, b, dev)
+        if up and cin % 64:
+            with pytest.raises(ValueError):       # no upsample form on the explicit-im2col path: refused, not wrong
+                ops.conv2d(ops.nchw_to_nhwc(x.to(dev)), cw, stride=stride, up=up)
+            up = False
+        y = ops.conv2d(ops.nchw_to_nhwc(x.to(dev)), cw, stride=stride, up=up)
+        xin = F.interpolate(x, scale_factor=2.0, mode='nearest') if up else x
+        want = F.conv2d(xin, w, b, stride=stride, padding=1)
+        assert (y.H, y.W) == tuple(want.shape[-2:]), (case, y.H, y.W, want.shape)
+        got = y.t.float().cpu().view(B, y.H, y.W, -1)[..., :cout].permute(0, 3, 1, 2)
+        err = (got - want).abs()
+        assert bool((err <= 3e-3 + 3e-3 * want.abs()).all()), ('conv', B, cin, cout, H, W, stride, up, float(err.max()))
+
+
 def test_gemm_bias2_and_geglu(dev):
     from flexdiffuse_amd import ops
     B, HW, K, C = 4, 96, 320, 320
