@@ -172,7 +172,9 @@ class FlexPipeline():
             self.unet.forward_nhwc(latents, t_static, ctx, rep=rep)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: only THIS thread's calls are checked against the capture -- a process-group watchdog thread
+            # (RCCL, N > 1) polling its events must not invalidate it
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 eps = self.unet.forward_nhwc(latents, t_static, ctx, rep=rep)
             entry = (graph, t_static, eps, ctx)
             self._graphs = {key: entry}          # keep one graph (its pool holds GBs)

@@ -96,3 +96,76 @@ def test_reference_export_names():
     sig = inspect.signature(F.FlexPipeline.__call__)
     assert list(sig.parameters)[1:10] == ['guide', 'init_image', 'init_size', 'strength', 'eta',
                                           'generator', 'output_type', 'return_dict', 'debug']
+
+
+def test_scheduler_config_and_pipeline_constructor_rewrite():
+    '''pipeline/flex.py:57-70: a scheduler config that HAS a steps_offset other than 1 is rewritten to 1 with a
+    DeprecationWarning; a config without the key (diffusers 0.3.0, and this package's steps_offset=0 schedulers) is left
+    alone.  No device needed: the constructor launches nothing.'''
+    import types
+    import warnings
+    from flexdiffuse_amd.pipeline.flex import FlexPipeline
+    from flexdiffuse_amd.scheduler import PNDMScheduler
+    s0, s1, s2 = DDIMScheduler(), DDIMScheduler(steps_offset=1), PNDMScheduler(steps_offset=2)
+    assert not hasattr(s0.config, 'steps_offset') and s0.config.get('steps_offset', 0) == 0
+    assert s1.config.steps_offset == 1 and s1.config['num_train_timesteps'] == 1000
+    with pytest.raises(AttributeError):
+        s0.config.no_such_key
+    unet = types.SimpleNamespace(device=torch.device('cpu'))
+    for sched, want_warn, want_off in ((s0, False, 0), (s1, False, 1), (s2, True, 1)):
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter('always')
+            pipe = FlexPipeline(None, None, None, unet, sched)
+        assert any(w.category is DeprecationWarning for w in wl) == want_warn
+        assert pipe.scheduler.config.get('steps_offset', 0) == want_off
+        pipe.scheduler.set_timesteps(10)
+        assert int(pipe.scheduler.timesteps[-1]) == want_off
+    assert pipe.pause_gc is False and pipe.use_plan is True
+
+
+def test_runner_constructor_refusals_and_from_directories(tmp_path):
+    '''`Runner(local=False)` cannot be served (no hub access); directories must come in pairs; a checkpoint directory
+    without a tokenizer is refused before any model is built.  CPU only: every refusal happens before the device is used.'''
+    import os
+    from safetensors.torch import save_file
+    from flexdiffuse_amd import Runner, build
+    with pytest.raises(RuntimeError):
+        Runner(local=False, device='cuda')
+    with pytest.raises(ValueError):
+        Runner(True, 'cuda', sd_dir=str(tmp_path))
+    sds = build.synthetic_state_dicts('mini_bpe', seed=1)
+    for sub in ('unet', 'vae'):
+        os.makedirs(tmp_path / 'sd' / sub)
+        save_file({k: v.contiguous() for k, v in sds[sub].items()},
+                  str(tmp_path / 'sd' / sub / 'diffusion_pytorch_model.safetensors'))
+    os.makedirs(tmp_path / 'clip')
+    save_file({k: v.contiguous() for k, v in sds['clip'].items()}, str(tmp_path / 'clip' / 'model.safetensors'))
+    with pytest.raises(FileNotFoundError):
+        build.from_directories(str(tmp_path / 'sd'), str(tmp_path / 'clip'), preset='mini_bpe', device='cuda')
+    assert build.configs('mini_bpe')[2].text.vocab_size == 1024
+
+
+def test_devmon_and_bench_clock_fields_without_a_gpu():
+    '''tools/devmon.py never touches HIP and degrades to "no source" where no AMD GPU is visible; bench.devmon_collect
+    turns whatever the sampler child printed into the `device.*` fields (None when there is nothing).'''
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'devmon.py'), '--probe'], capture_output=True, timeout=120)
+    rec = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert set(rec) == {'source', 'errors', 'sample'}
+    sys.path.insert(0, root)
+    import bench
+    assert bench.devmon_collect(None, 0.0, 1.0)['avg_sclk_mhz'] is None
+    t0 = time.time()
+    fake = subprocess.Popen([sys.executable, '-c',
+                             'import sys, json, time; sys.stdin.read(); t = %r; '
+                             'print(json.dumps({"source": "fake", "errors": [], "samples": '
+                             '[[t + 0.1, 2000.0, 1000.0, 1900.0], [t + 0.2, 2100.0, 1100.0, 1900.0], [t + 9.0, 50.0, 90.0, 900.0]]}))' % t0],
+                            stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+    out = bench.devmon_collect(fake, t0, t0 + 1.0)
+    assert out['clock_source'] == 'fake' and out['clock_samples'] == 2
+    assert out['avg_sclk_mhz'] == 2050.0 and out['avg_power_w'] == 1050.0 and out['max_sclk_mhz'] == 2100.0
