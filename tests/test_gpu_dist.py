@@ -85,16 +85,20 @@ def test_bench_launches_eight_ranks():
     model, runs its shard through its own launch plan and takes part in the gather (gloo: RCCL
     refuses eight ranks on one device).  Under test: eight concurrent host loops, the launcher, the
     sharding and the gather of 8 x batch samples.'''
-    line = _bench(['--gpus', '8'] + MINI, FD_BENCH_SHARE_GPU='1', FD_DIST_BACKEND='gloo')
+    line = _bench(['--gpus', '8', '--launch', 'plan'] + MINI, FD_BENCH_SHARE_GPU='1', FD_DIST_BACKEND='gloo')
     assert line['n_gpus'] == 8 and line['rccl_ranks'] == 0 and line['dist_backend'] == 'gloo'
     assert line['config']['images_per_step'] == 16 and line['value'] > 0
     assert line['host_margin']['launch'] == 'plan' and line['host_margin']['launches_per_forward'] > 50
+    # and the bench's default launch mode (HIP-graph replay; capture per rank) in the same 8-rank shape
+    line = _bench(['--gpus', '8'] + MINI, FD_BENCH_SHARE_GPU='1', FD_DIST_BACKEND='gloo')
+    assert line['n_gpus'] == 8 and line['value'] > 0
+    assert line['host_margin']['launch'] == 'graph' and line['config']['launch_note'] is None
 
 
 def test_bench_single_rank_rccl_line():
     '''N = 1 through the RCCL path (FD_FORCE_DIST=1): same line shape, rccl_ranks 1, and the
     roofline / all_gather objects are present and self-consistent.'''
-    line = _bench(['--gpus', '1'] + MINI, FD_FORCE_DIST='1', MASTER_PORT='29533')
+    line = _bench(['--gpus', '1', '--launch', 'plan'] + MINI, FD_FORCE_DIST='1', MASTER_PORT='29533')
     assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1 and line['dist_backend'] == 'nccl'
     assert line['all_gather']['backend'].startswith('RCCL') and line['all_gather']['bytes_per_rank'] > 0
     hm = line['host_margin']
