@@ -1928,6 +1928,8 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         case 15: rc = launch_epi<256, 256, 4, 2, 4, 110>(g, batch, st); break;  // 16 waves, 64x64 wave tiles
         case 16: rc = launch_epi<256, 320, 4, 2, 4, 294>(g, batch, st); break;  // 16 waves, 64x80 wave tiles
         case 20: rc = launch_epi<128, 160, 4, 3, 2, 38 + 256>(g, batch, st); break;   // tile 9 with 3 LDS stages
+        // (a 3-stage form of tile 13 -- launch_epi<256, 160, 8, 3, 2, 6>: 3 x 53,248 B + bias tiles = 162,304 B, it does fit the 160 KiB --
+        //  measured identical to the 2-stage tile on every deep-level convolution, profiles/r04_session_ab.txt sec. 5: not instantiated)
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }
     if (rc == FD_OK && g.split_k > 1) {
