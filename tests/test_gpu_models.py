@@ -769,6 +769,40 @@ def test_hip_graph_replay_matches_eager(mini, dev):
         pipe.use_graph = False
 
 
+def test_planned_unet_under_generic_schedulers_equals_the_protocol_path(mini, dev):
+    '''SimpleGuide with a scheduler other than plain DDIM (PNDM -- what the reference's Runner passes, utils.py:70 --, K-LMS,
+    DDIM with eta): the UNet forward comes from the launch plan / HIP graph (`planned` in FlexPipeline.__call__) and only the
+    scheduler arithmetic stays generic.  Bit-identical latents to the reference protocol path (`guide.noise_pred` +
+    `scheduler.step`, plan and graph off), in both launch modes, float LMS timesteps included.'''
+    from flexdiffuse_amd import SimpleGuide
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from flexdiffuse_amd.scheduler import DDIMScheduler, LMSDiscreteScheduler, PNDMScheduler
+    sds, pipe, clip, tok, _ = mini
+    enc = CLIPEncoder(clip, tok)
+    keep = pipe.scheduler
+
+    def run(sched, eta, seed):
+        pipe.scheduler = sched
+        g = SimpleGuide(enc, pipe.unet, 7.5, 5, enc.prompt(['a photo of a turtle', 'zeus, oil painting']))
+        torch.manual_seed(3)        # DDIM eta > 0 draws its variance noise from the global CPU generator
+        pipe(guide=g, init_size=(64, 64), eta=eta, generator=torch.Generator('cpu').manual_seed(seed), output_type='np')
+        return pipe.last_latents.clone()
+    try:
+        for make, eta in ((PNDMScheduler, 0.0), (LMSDiscreteScheduler, 0.0), (DDIMScheduler, 0.5)):
+            pipe.use_plan, pipe.use_graph = False, False
+            want = run(make(), eta, 11)
+            pipe.use_plan, pipe._plans = True, {}
+            got_plan = run(make(), eta, 11)
+            pipe.use_graph, pipe._graphs = True, {}
+            got_graph = run(make(), eta, 11)
+            pipe.use_graph = False
+            assert torch.equal(want, got_plan), make.__name__
+            assert torch.equal(want, got_graph), make.__name__
+            assert float(want.abs().max()) > 0.1 and bool(torch.isfinite(want).all())
+    finally:
+        pipe.scheduler, pipe.use_plan, pipe.use_graph = keep, True, False
+
+
 def test_launch_plan_replay_matches_eager_front(mini, dev):
     """Default launch mode: the UNet forward of the fused loop is replayed from its recorded launch
     plan (hip.Plan / fd_plan_*).  Bit-identical latents to the eager Python front, also when prompts,
