@@ -243,7 +243,9 @@ __global__ __launch_bounds__(NT) void k_gn_slab(const half_t* __restrict__ x, ha
     float* part = sm;                 // [PL][CB/2][2]  (sum, sumsq) per channel pair
     float* part2 = sm + PL * CB;      // [J][CB/2][2]
     float* gst = part2 + J * CB;      // [GB][2] mean, rstd
-    const int b = blockIdx.y, ch0 = blockIdx.x * CB, tid = threadIdx.x;
+    // grid (B, G / GB): consecutive workgroup ids go round-robin over the 8 XCDs, so with the SAMPLE as the fast index all group
+    // blocks of one sample -- whose 40..160-byte row segments share 128-byte lines -- run on one XCD and meet in its L2
+    const int b = blockIdx.x, ch0 = blockIdx.y * CB, tid = threadIdx.x;
     const int cc = tid % c8, pl = tid / c8;
     const bool active = pl < PL;
     // uniform 64-bit base + 32-bit per-lane offsets (keeps the address math out of VGPR pairs)
@@ -368,7 +370,9 @@ static bool gn_try_slab(const void* x, void* y, const float* gamma, const float*
             attr_set = true;
         }
         fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 4.0);
-        hipLaunchKernelGGL((k_gn_slab<NT, NV>), dim3(G / GB, B), dim3(NT), lds, st, (const half_t*)x,
+        // grid (B, G / GB), sample fastest (round 4): -10..-20 % on every slab shape against (G / GB, B)
+        // (profiles/r04_session_ab.txt sec. 8: 16x1024x640 17.6 -> 14.0 us, 16x256x1280 10.2 -> 8.3 us)
+        hipLaunchKernelGGL((k_gn_slab<NT, NV>), dim3(B, G / GB), dim3(NT), lds, st, (const half_t*)x,
                            (half_t*)y, gamma, beta, HW, C, G, GB, eps, silu, ldx);
         fd_prof_end(FD_FAMILY_GROUPNORM, st);
         *rc = hipGetLastError() == hipSuccess ? FD_OK : FD_EHIP;
