@@ -16,7 +16,11 @@ oracle/__init__.py); this file pins nothing new, it only caches the oracle's own
 `--guidance clustered_threshold` writes c3_oracle.npz: the same sample under BASELINE configs[2]'s guidance
 parameters (Clustered 0.25 + Threshold (0.75, 0.25), linear off, max 0.35, header cap 0: bench.py GUIDANCE).
 
-Usage:  python tests/golden/make_c2_oracle.py [--steps 50] [--size 512] [--guidance linear|clustered_threshold]
+`--scheduler pndm|lms` writes c2_pndm_oracle.npz / c2_lms_oracle.npz: the headline sample under the scheduler the reference's harness
+really passes (SD-v1-4 ships PNDM, utils.py:70; PLMS: 51 UNet evaluations for 50 steps) and under K-LMS (pipeline/flex.py:236-238, 270-274
+sigma scaling), through oracle/sched_ref.py; the guided embeddings are taken from c2_oracle.npz.
+
+Usage:  python tests/golden/make_c2_oracle.py [--steps 50] [--size 512] [--guidance linear|clustered_threshold] [--scheduler ddim|pndm|lms]
 '''
 import argparse
 import hashlib
@@ -51,11 +55,14 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--guidance', default='linear', choices=['linear', 'clustered_threshold'])
+    ap.add_argument('--scheduler', default='ddim', choices=['ddim', 'pndm', 'lms'])
     ap.add_argument('--out', default=None)
     ap.add_argument('--threads', type=int, default=0)
     args = ap.parse_args()
     if args.threads:
         torch.set_num_threads(args.threads)
+    if args.scheduler != 'ddim':
+        return other_scheduler(args)
     import bench
     embeds_kw = C2['embeds_kw'] if args.guidance == 'linear' else bench.GUIDANCE[args.guidance]
     if args.out is None:
@@ -87,6 +94,42 @@ def main():
         prompt=np.array(prompt))
     print(f'wrote {args.out}: embeds {t_embed:.1f} s, {args.steps}-step loop {t_loop:.1f} s on '
           f'{torch.get_num_threads()} threads; latents std {float(lat.std()):.3f}')
+
+
+def other_scheduler(args):
+    '''The headline sample (Linear guidance) under PNDM / K-LMS: embeddings from c2_oracle.npz, loop from oracle/sched_ref.py.'''
+    from flexdiffuse_amd import build
+    from flexdiffuse_amd.tokenizer import SyntheticTokenizer
+    from oracle import clip_ref, pipeline_ref, sched_ref
+    assert args.guidance == 'linear' and args.size == 512
+    out = args.out or os.path.join(HERE, f'c2_{args.scheduler}_oracle.npz')
+    sds = build.synthetic_state_dicts('sd15', seed=0)
+    ucfg, vcfg, ccfg = build.configs('sd15')
+    tok = SyntheticTokenizer(vocab_size=ccfg.text.vocab_size, model_max_length=ccfg.text.max_position_embeddings)
+    o = np.load(os.path.join(HERE, 'c2_oracle.npz'))
+    prompt, img, lat0 = c2_inputs(args.size)
+    assert hashlib.sha256(lat0.numpy().tobytes()).digest() == o['lat0_sha'].tobytes() and str(o['prompt']) == prompt
+    embeds = torch.from_numpy(o['embeds'])
+    text_sd = {k: v for k, v in sds['clip'].items() if k.startswith('text_model')}
+    uncond = clip_ref.text_hidden(text_sd, ccfg, tok('').input_ids)
+    n = [0]
+    t0 = time.time()
+
+    def eps_fn(x, t):
+        n[0] += 1
+        print(f'  evaluation {n[0]} t={float(t):.1f} |x|max={float(x.abs().max()):.3f} ({time.time() - t0:.0f} s)', flush=True)
+        return pipeline_ref.noise_pred(sds['unet'], ucfg, x, t, embeds, uncond, C2['guidance'])
+    if args.scheduler == 'pndm':
+        lat, used = sched_ref.pndm_loop(eps_fn, lat0, args.steps)
+        extra = dict(timesteps=np.array(used, dtype=np.int64))
+    else:
+        lat, sigmas = sched_ref.lms_loop(eps_fn, lat0, args.steps)
+        extra = dict(sigmas=np.asarray(sigmas, dtype=np.float64))
+    np.savez_compressed(out, latents=lat.numpy().astype(np.float32), evaluations=np.array([n[0]]),
+                        lat0_sha=np.frombuffer(hashlib.sha256(lat0.numpy().tobytes()).digest(), dtype=np.uint8),
+                        steps=np.array([args.steps]), size=np.array([args.size]), cpu_seconds=np.array([time.time() - t0]),
+                        threads=np.array([torch.get_num_threads()]), prompt=np.array(prompt), **extra)
+    print(f'wrote {out}: {n[0]} CFG evaluations in {time.time() - t0:.0f} s; latents std {float(lat.std()):.3f}')
 
 
 if __name__ == '__main__':

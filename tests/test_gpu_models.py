@@ -424,6 +424,47 @@ def test_sd15_c3_clustered_threshold_psnr(sd15, dev):
     assert out.images.shape == (1, size, size, 3) and p >= 40.0, p
 
 
+@pytest.mark.parametrize('kind', ['pndm', 'lms'])
+def test_sd15_c2_under_pndm_and_lms_psnr(sd15, dev, kind):
+    '''The headline sample at FULL size (SD1.5, 512x512, 50 steps, CFG 8, Linear image guidance) under the scheduler the
+    reference's harness really passes -- SD-v1-4 ships PNDM (utils.py:70; PLMS: 51 UNet evaluations) -- and under K-LMS with the
+    pipeline's sigma scaling (pipeline/flex.py:236-238, 270-274): device pipeline (UNet forward from the launch plan, scheduler
+    arithmetic through the generic protocol) vs the CPU oracle's final latents cached by
+    `tests/golden/make_c2_oracle.py --scheduler pndm|lms` (oracle/sched_ref.py, parity unpinned like the rest of diffusers);
+    final-image PSNR >= 40 dB.'''
+    path = os.path.join(GOLDEN, f'c2_{kind}_oracle.npz')
+    if not os.path.exists(path):
+        pytest.skip(f'{path} not generated')
+    import hashlib
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_c2_oracle import C2, c2_inputs
+    from flexdiffuse_amd import FlexPipeline, Guide, LMSDiscreteScheduler, PNDMScheduler, SimpleGuide
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from oracle import pipeline_ref
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = sd15
+    o = np.load(path)
+    steps, size = int(o['steps'][0]), int(o['size'][0])
+    prompt, img, lat0 = c2_inputs(size)
+    assert hashlib.sha256(lat0.numpy().tobytes()).digest() == o['lat0_sha'].tobytes()
+    sched = PNDMScheduler() if kind == 'pndm' else LMSDiscreteScheduler()
+    p2 = FlexPipeline(pipe.vae, clip, tok, pipe.unet, sched).to(dev)
+    embeds = Guide(clip, tok, device='cuda').embeds(prompt=prompt, guide=img, **C2['embeds_kw'])
+    out = p2(guide=SimpleGuide(CLIPEncoder(clip, tok), pipe.unet, C2['guidance'], steps, embeds), init_size=(size, size),
+             latents=lat0, output_type='np')
+    if kind == 'pndm':
+        assert [int(t) for t in o['timesteps']] == [int(t) for t in sched.timesteps] and int(o['evaluations'][0]) == steps + 1
+    else:
+        assert np.allclose(o['sigmas'], sched.sigmas) and int(o['evaluations'][0]) == steps
+    lat_ref = torch.from_numpy(o['latents'])
+    img_ref = pipeline_ref.decode_image(sds['vae'], vcfg, lat_ref)
+    p = pipeline_ref.psnr(p2.last_images.cpu(), img_ref)
+    print(f'SD1.5 c2 sample under {kind.upper()}: latent rel err {relerr(p2.last_latents, lat_ref):.4f}, PSNR {p:.1f} dB, '
+          f'image std {float(img_ref.std()):.3f}')
+    assert out.images.shape == (1, size, size, 3) and float(img_ref.std()) > 0.02
+    assert p >= 40.0, p
+
+
 def _cached_oracle_psnr(name, dev, pipe, clip, tok, sds, vcfg):
     '''Device path of sample 0 of BASELINE configs[3] / configs[4] against the CPU fp32 oracle's final latents
     cached by tests/golden/make_c45_oracle.py (its 60 / 100 UNet forwards at 96x96 take 20-35 CPU-minutes);
