@@ -965,6 +965,47 @@ def test_composite_guide_vs_oracle(mini, dev):
     assert e < 2e-2, e
 
 
+def test_sd15_composite_guide_full_size_psnr(sd15, dev):
+    '''CompositeGuide at FULL size (reference composition/guide.py:32-139 through utils.py:168-207's recipe): SD1.5,
+    512x512, 20 DDIM steps, CFG 8, a background prompt and two entity boxes (one clipped by the canvas) -- every step one UNet batch over
+    [uncond | background | entities], the region blend on the device (fd_region_blend_f32) and the CFG combine, through the generic
+    GuideBase protocol of FlexPipeline -- against the CPU oracle's final latents cached by tests/golden/make_composite_oracle.py; final-image
+    PSNR >= 40 dB, and the entity regions really differ from a background-only run.'''
+    path = os.path.join(GOLDEN, 'composite_oracle.npz')
+    if not os.path.exists(path):
+        pytest.skip('tests/golden/composite_oracle.npz not generated')
+    import hashlib
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_composite_oracle import COMPOSITE as c
+    from flexdiffuse_amd.composition import CompositeGuide, EntitySchema, Schema
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from oracle import pipeline_ref
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = sd15
+    o = np.load(path)
+    enc = CLIPEncoder(clip, tok)
+    schema = Schema(c['background'], '', '', (0.0, 1.0), [EntitySchema(p, off, size, blend) for p, off, size, blend in c['entities']])
+    h = c['size'] // 8
+    lat0 = torch.randn((1, 4, h, h), generator=torch.Generator('cpu').manual_seed(c['seed']))
+    assert hashlib.sha256(lat0.numpy().tobytes()).digest() == o['noise_sha'].tobytes()
+    guide = CompositeGuide(enc, pipe.unet, c['guidance'], schema, c['steps'])
+    out = pipe(guide=guide, init_size=(c['size'], c['size']), generator=torch.Generator('cpu').manual_seed(c['seed']), output_type='np')
+    assert [int(t) for t in o['timesteps']] == [int(t) for t in pipe.scheduler.timesteps]
+    lat_ref = torch.from_numpy(o['latents'])
+    img_ref = pipeline_ref.decode_image(sds['vae'], vcfg, lat_ref)
+    img_dev = pipe.last_images.cpu()
+    p = pipeline_ref.psnr(img_dev, img_ref)
+    # background only (no entities): the boxes must have changed the image
+    pipe(guide=CompositeGuide(enc, pipe.unet, c['guidance'], Schema(c['background'], '', '', (0.0, 1.0), []), c['steps']),
+         init_size=(c['size'], c['size']), generator=torch.Generator('cpu').manual_seed(c['seed']), output_type='np')
+    moved = float((pipe.last_images.cpu() - img_dev).abs().mean())
+    print(f'CompositeGuide at 512x512 ({len(c["entities"])} entities, {c["steps"]} steps): PSNR {p:.1f} dB; '
+          f'entities moved the image by {moved:.4f}')
+    assert out.images.shape == (1, c['size'], c['size'], 3) and float(img_ref.std()) > 0.02
+    assert moved > 1e-3, 'the entity boxes changed nothing'
+    assert p >= 40.0, p
+
+
 def test_sd15_full_size_unet_properties(sd15, dev):
     """BASELINE configs[1] sizes (SD1.5 UNet, 64x64 latents, CFG batch 16): one sample checked
     against the CPU oracle, and size-independent properties on the whole batch -- sample
