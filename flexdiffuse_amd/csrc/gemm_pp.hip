@@ -1,0 +1,504 @@
+// Deep-pipelined fp16 MFMA GEMM / implicit-GEMM convolution main loop for gfx950 ("ping-pong", tile ids 30..).
+//
+// Serves the same contraction as gemm.hip (C = epilogue(sum_k A(m,k) W[n][k]), same GemmArgs, same fused epilogues) for
+// the shapes that dominate the UNet forward (3x3 convolutions, GEGLU, FF-out): reference call site pipeline/guide.py:56-58
+// (the single unet(...) call).  Structure (measured first in tools/micro/gemm_8phase.hip, profiles/r05_micro_8phase.txt:
+// 1459 TFLOP/s at 4096^3 / 1603 at 8192^3 on random fp16 against 1353 / 1287 for the 2-barrier loop of gemm.hip):
+//
+//   * 8 wavefronts as WM_ x WN_, big wave tiles (MI x NI fragments of 16x16, e.g. 128x80), one workgroup per CU.
+//   * LDS = a ring of 8 pieces: 2 K-tiles x { A0: the first MI/2 row fragments of every wave row, B0: the first ceil(NI/2)
+//     column fragments of every wave column, B1: the remaining column fragments, A1: the remaining rows }.  Every piece is
+//     filled by LDS-DMA (buffer_load_dwordx4 ... lds, 8 rows x 128 B per wave instruction, source-side XOR swizzle) and stays
+//     in flight ACROSS barriers: the only VM wait in the loop is a counted s_waitcnt vmcnt(one K-tile's worth), never 0.
+//   * A K-tile is four phases = the four (row half, column half) quadrants of the wave tile; a phase is
+//       [ds_read_b128 of the new operand half + DMA of the piece six pieces ahead + vmcnt]  s_barrier  [MFMAs]  s_barrier
+//     phase 0 reads A0 + B0, phase 1 B1, phase 2 A1, phase 3 nothing (B0 stays in registers).
+//   * The two halves of the workgroup (waves 0-3 / 4-7: one wave of each per SIMD) run ONE BARRIER APART, so on every SIMD
+//     one wave is inside its MFMA section while its partner issues the reads and DMAs of its next one.
+//   Ordering (MI355X_MICROARCH.md, two waves per SIMD, item 7): a piece is read one phase after the phase whose counted
+//   vmcnt retired it in every wave (RAW), and overwritten no sooner than two phases after its last ds_read (WAR).
+//
+// DMA addressing is scalar: an 8-row DMA group is 8 consecutive rows of A (or 8 consecutive pixels of one image row for a
+// convolution: Wo % 8 == 0), so the per-lane part of the source offset is a constant and everything else (row base, filter
+// tap, K offset) rides in the scalar soffset; zero padding is a per-lane select on the column only.  Requirements (checked by
+// fd_gemm_pp_ok, everything else stays on gemm.hip's kernels): full tiles, K % 64 == 0, convolutions with Wo % 8 == 0 and no
+// fused upsample.
+#include "gemm_epilogue.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+template <int WM_, int WN_, int MI, int NI, bool CONV, int EPI, bool HAS_K2>
+__global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_bytes, unsigned w_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(WM_ * WN_ == 8 && MI % 2 == 0, "8 waves; the row halves must be equal");
+    constexpr int WTM = MI * 16, WTN = NI * 16, BM = WM_ * WTM, BN = WN_ * WTN;
+    constexpr int MH = MI / 2, NI0 = (NI + 1) / 2, NI1 = NI / 2;
+    constexpr int PA = WM_ * MH * 16, PB0 = WN_ * NI0 * 16, PB1 = WN_ * NI1 * 16;   // piece rows
+    constexpr int OA0 = 0, OB0 = PA * 128, OB1 = OB0 + PB0 * 128, OA1 = OB1 + PB1 * 128, STAGE = OA1 + PA * 128;
+    constexpr int GA = PA / 8, GB0 = PB0 / 8, GB1 = PB1 / 8;                        // 8-row DMA groups per piece
+    constexpr int CA = (GA + 7) / 8, CB0 = (GB0 + 7) / 8, CB1 = (GB1 + 7) / 8;      // DMA instructions per wave and piece
+    static_assert(GA % 8 == 0 && GB1 % 8 == 0, "only B0 may leave some waves one DMA short");
+    // one K-tile's worth of this wave's DMAs (waves with an extra B0 group wait a little more than they must: safe)
+    constexpr int INFLIGHT = 2 * (GA / 8) + GB0 / 8 + GB1 / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+#ifdef FD_PP_STAMPS   // diagnostic build (tools/pp_stamps.py): s_memtime stamps of every wave into the split-K workspace
+    const unsigned long long ts_start = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
+    unsigned long long ts_a[4] = {0, 0, 0, 0}, ts_b[4] = {0, 0, 0, 0}, ts_d[4] = {0, 0, 0, 0};
+#define PP_STAMP(X) X = __builtin_amdgcn_s_memtime();
+#else
+#define PP_STAMP(X)
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN_, wn = wave % WN_;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nb = g.tiles_m * g.tiles_n;
+    int id = blockIdx.x;
+    {
+        const int q = nb >> 3, r = nb & 7, xcd = id & 7, slot = id >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tile_n = id % g.tiles_n, tile_m = id / g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int z = blockIdx.z;
+    const int kslice = blockIdx.y;
+    // conv: the descriptor starts pad_l pixels BEFORE the tensor, so that the scalar offset of a row group whose leftmost tap
+    // column is -pad_l stays >= 0 (the lanes of such columns never load: their voffset is out of range)
+    const int pad_t = CONV ? (g.phase ? 1 - (z >> 1) : g.pad_t) : 0, pad_l = CONV ? (g.phase ? 1 - (z & 1) : g.pad_l) : 0;
+    const int a_shift = pad_l * g.Cin;   // halfs
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(g.A + (size_t)z * g.strideA - a_shift), 0, a_bytes + 2u * (unsigned)a_shift, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(g.W + (size_t)z * g.strideW), 0, w_bytes, 0x00020000);
+    // (the appended phase over A2 -- HAS_K2 -- is a compile-time variant: its descriptor and branches cost ~10 SGPRs, and a
+    // convolution kernel short of SGPRs keeps wave-uniform DMA offsets in VGPRs and waterfalls every LDS-DMA)
+    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(HAS_K2 ? g.A2 : g.A), 0, HAS_K2 ? g.a2_bytes : 0u, 0x00020000);
+
+    // ---- this tile's bias / per-sample bias -> LDS, ahead of the first pieces (see k_gemm_f16_dma) -------------------
+    float* bias_s = reinterpret_cast<float*>(smem + 2 * STAGE);
+    if ((g.bias && g.bias_lds) || (EPI != 0 && EPI != 7)) {
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(g.bias ? (const void*)(g.bias + (size_t)z * g.strideBias) : (const void*)g.W), 0, g.bias ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
+        if (wave * 64 + lane < BN)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(bias_s + wave * 64), 4,
+                                                     (unsigned)(n0 + wave * 64 + lane) * 4u, 0, 0, 0);
+    }
+    const int b_first = m0 / g.rows_per_batch;
+    const bool b2_staged = g.bias2 && g.bias_lds && (min(m0 + BM, g.M) - 1) / g.rows_per_batch == b_first;
+    if (b2_staged || (EPI != 0 && EPI != 7)) {
+        const __amdgpu_buffer_rsrc_t rsB2 = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(b2_staged ? (const void*)(g.bias2 + (size_t)b_first * g.ldb2) : (const void*)g.W), 0,
+            b2_staged ? (unsigned)((g.N + 3) & ~3) * 4u : 0u, 0x00020000);
+        if (wave * 64 + lane < BN)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(bias_s + BN + wave * 64), 4,
+                                                     (unsigned)(n0 + wave * 64 + lane) * 4u, 0, 0, 0);
+    }
+
+    // ---- DMA source addressing: lane constants + per-group scalars -----------------------------------------------------
+    // Scalar registers are the scarce resource of this kernel (a convolution short of SGPRs keeps wave-uniform DMA offsets in
+    // VGPRs and then WATERFALLS every LDS-DMA): per DMA group only (pixel index, packed y|x) persist, the K-tile being staged
+    // is four counters, everything else is derived where it is used.
+    const int rsub = lane >> 3;                            // row inside the 8-row group
+    const unsigned ck16 = (unsigned)(((lane & 7) ^ rsub) << 4);   // byte offset of the source chunk of this lane's LDS slot
+    constexpr unsigned OOB = 0x80000000u;                 // voffset past every tensor: the load returns zeros
+    const unsigned w_lane = (unsigned)(rsub * g.ldw) * 2u + ck16;
+    // first row of this wave's DMA group i of A piece mi
+#define PP_GROUP_ROW(MIH, I) (m0 + (((I) * 8 + wave) * 8 / (MH * 16)) * WTM + (MIH) * MH * 16 + ((I) * 8 + wave) * 8 % (MH * 16))
+    // conv: pixel index of the group's first tap column relative to the (shifted) descriptor, (y + 0x4000) << 16 | (x + 0x4000)
+    // of its first tap; linear: the row index
+    int sA_px[2][CA], sA_yx[2][CA];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int i = 0; i < CA; ++i) {
+            const int m = PP_GROUP_ROW(mi, i);
+            if (CONV) {
+                const int hw = g.Ho * g.Wo;
+                const int b = m / hw, rem = m - b * hw;
+                const int oy = rem / g.Wo, ox0 = rem - oy * g.Wo;
+                const int y = oy * g.stride - pad_t, x = ox0 * g.stride - pad_l;
+                sA_yx[mi][i] = ((y + 0x4000) << 16) | (x + 0x4000);
+                sA_px[mi][i] = (b * g.Hi + y) * g.Wi + x + pad_l;
+            } else {
+                sA_yx[mi][i] = 0;
+                sA_px[mi][i] = m;
+            }
+        }
+    // first W row of this wave's DMA group i of piece B0 / B1
+#define PP_B_ROW(NIH, I) (n0 + ((((I) * 8 + wave) * 8) / (((NIH) ? NI1 : NI0) * 16)) * WTN + ((NIH) ? NI0 * 16 : 0) + (((I) * 8 + wave) * 8) % (((NIH) ? NI1 : NI0) * 16))
+
+    // ---- K range of this workgroup; the K-tile whose pieces are being staged ------------------------------------------
+    const int nkc = g.K / BK;                            // K-tiles of the convolution / GEMM proper
+    const int nk_all = nkc + (HAS_K2 ? g.K2 / BK : 0);   // + the appended phase over A2 (a compile-time variant)
+    const int kt_per = (nk_all + g.split_k - 1) / g.split_k;
+    const int kt0 = kslice * kt_per;
+    const int nk = min(nk_all, kt0 + kt_per);
+    const int nkl = nk - kt0;
+    const int ntaps = CONV ? g.K / g.Cin : 1;
+    // convolution: K-tiles visit all filter taps of one 64-channel slice before the next slice (the taps re-read the same input
+    // rows, so the re-use distance in the XCD's L2 is one K-tile; 5-9 % faster than (tap, slice) order on this loop)
+    int t_cur = kt0, c_kh = 0, c_kw = 0, c_ci0 = 0;
+    if (CONV && kt0 > 0 && kt0 < nkc) {
+        const int tap = kt0 % ntaps;
+        c_ci0 = (kt0 / ntaps) * BK;
+        c_kh = tap / g.KW;
+        c_kw = tap - c_kh * g.KW;
+    }
+#define PP_ADVANCE()                                                                                        \
+    {                                                                                                       \
+        ++t_cur;                                                                                            \
+        if (CONV) {                                                                                         \
+            const bool wrap_w_ = c_kw + 1 == g.KW;                                                          \
+            const bool wrap_h_ = wrap_w_ && (c_kh + 1) * g.KW == ntaps;                                     \
+            c_kw = wrap_w_ ? 0 : c_kw + 1;                                                                  \
+            c_kh = wrap_h_ ? 0 : (wrap_w_ ? c_kh + 1 : c_kh);                                               \
+            c_ci0 = wrap_h_ ? c_ci0 + BK : c_ci0;                                                           \
+        }                                                                                                   \
+    }
+    // The appended phase reads plain rows A2[m][lda2].  For a convolution it is staged as the CENTRE tap of a second NHWC
+    // tensor with lda2 channels (same spatial size, stride 1: row m is pixel (b, oy, ox)), so that one address form serves both:
+    //   soffset = pixel index * bytes per pixel + K-tile offset,   lane part = rsub * pixel stride + chunk
+#define PP_IS_A2() (HAS_K2 && t_cur >= nkc)
+    // The scalar operands of a piece's DMAs are PREPARED one phase ahead, behind that phase's MFMAs (the wave has issued
+    // them and would otherwise sit at the barrier while they execute): a LOAD section is then only ds_reads + DMA issue.
+    // Measured with the s_memtime stamps (tools/pp_stamps.py): with the address arithmetic inside the LOAD sections the
+    // A0 section took ~780 cycles against 256-384 of MFMAs in the partner wave.
+    int pA_soff[CA], pA_lim[CA], pB_soff[CB0];
+#define PP_PREP_A(MIH)                                                                                      \
+    {                                                                                                       \
+        const bool a2_ = PP_IS_A2();                                                                        \
+        const int ok_ = t_cur < nk ? 1 : 0;                                                                 \
+        int pixb_, asoff_, kh_;                                                                             \
+        if (CONV) {                                                                                         \
+            pixb_ = a2_ ? g.lda2 * 2 : g.Cin * 2;                                                           \
+            asoff_ = a2_ ? (pad_t * g.Wi * g.lda2 + (t_cur - nkc) * BK) * 2 : ((c_kh * g.Wi + c_kw) * g.Cin + c_ci0) * 2; \
+            kh_ = a2_ ? pad_t : c_kh;                                                                       \
+        } else {                                                                                            \
+            pixb_ = a2_ ? g.lda2 * 2 : g.lda * 2;                                                           \
+            asoff_ = (a2_ ? t_cur - nkc : t_cur) * BK * 2;                                                  \
+            kh_ = 0;                                                                                        \
+        }                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < CA; ++i) {                                                    \
+            pA_soff[i] = sA_px[MIH][i] * pixb_ + asoff_;                                                    \
+            if (CONV) {                                                                                     \
+                const int y_ = (sA_yx[MIH][i] >> 16) - 0x4000 + kh_;                                        \
+                pA_lim[i] = (ok_ != 0 && (unsigned)y_ < (unsigned)g.Hi) ? g.Wi : 0;                         \
+            } else {                                                                                        \
+                pA_lim[i] = (-ok_) & 0x7fffffff;                                                            \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+#define PP_PREP_B(NIH)                                                                                      \
+    {                                                                                                       \
+        const bool a2_ = PP_IS_A2();                                                                        \
+        const int wsoff_ = a2_ ? (g.K + (t_cur - nkc) * BK) * 2                                             \
+                               : (CONV ? ((c_kh * g.KW + c_kw) * g.Cin + c_ci0) * 2 : t_cur * BK * 2);      \
+        _Pragma("unroll") for (int i = 0; i < ((NIH) ? CB1 : CB0); ++i)                                     \
+            pB_soff[i] = PP_B_ROW(NIH, i) * g.ldw * 2 + wsoff_;                                             \
+    }
+#define PP_PREP(O)                                      \
+    {                                                   \
+        if ((O) == 0) { PP_ADVANCE(); PP_PREP_A(0); }   \
+        if ((O) == 1) { PP_PREP_B(0); }                 \
+        if ((O) == 2) { PP_PREP_B(1); }                 \
+        if ((O) == 3) { PP_PREP_A(1); }                 \
+    }
+    // column test of a (conv) row group: lane x = x0 + rsub * stride must lie in [0, pA_lim); pA_lim is 0 when the tap's row,
+    // or the whole K-tile, is out of range.  Linear rows: x == 0 < pA_lim.
+#define PP_ISSUE_A(MIH, PAR)                                                                                \
+    {                                                                                                       \
+        const bool a2_ = PP_IS_A2();                                                                        \
+        const int pixs_ = a2_ ? g.lda2 * 2 : (CONV ? g.stride * g.Cin * 2 : g.lda * 2);                     \
+        const int kw_ = a2_ ? pad_l : c_kw;                                                                 \
+        const unsigned lanev_ = (unsigned)(rsub * pixs_) + ck16;                                            \
+        _Pragma("unroll") for (int i = 0; i < CA; ++i) {                                                    \
+            char* dst_ = smem + (PAR) * STAGE + ((MIH) ? OA1 : OA0) + (i * 8 + wave) * 1024;                \
+            const int x0_ = CONV ? (sA_yx[MIH][i] & 0xffff) - 0x4000 + kw_ : 0;                             \
+            const bool in_ = (unsigned)(x0_ + (CONV ? rsub * g.stride : 0)) < (unsigned)pA_lim[i];          \
+            if (a2_)                                                                                        \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)dst_, 16, in_ ? lanev_ : OOB, pA_soff[i], 0, 0); \
+            else                                                                                            \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)dst_, 16, in_ ? lanev_ : OOB, pA_soff[i], 0, 0); \
+        }                                                                                                   \
+    }
+#define PP_ISSUE_B(NIH, PAR)                                                                                \
+    {                                                                                                       \
+        const unsigned wv_ = t_cur < nk ? w_lane : OOB;                                                     \
+        _Pragma("unroll") for (int i = 0; i < ((NIH) ? CB1 : CB0); ++i)                                     \
+            if ((NIH) || GB0 % 8 == 0 || i * 8 + wave < GB0)                                                \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(smem + (PAR) * STAGE + ((NIH) ? OB1 : OB0) + (i * 8 + wave) * 1024), 16, \
+                                                         wv_, pB_soff[i], 0, 0);                            \
+    }
+    // piece order of a K-tile: 0 A0, 1 B0, 2 B1, 3 A1
+#define PP_ISSUE(O, PAR)                                \
+    {                                                   \
+        if ((O) == 0) { PP_ISSUE_A(0, PAR); }           \
+        if ((O) == 1) { PP_ISSUE_B(0, PAR); }           \
+        if ((O) == 2) { PP_ISSUE_B(1, PAR); }           \
+        if ((O) == 3) { PP_ISSUE_A(1, PAR); }           \
+    }
+
+    // ---- fragment reads: row r keeps k-chunk c at 16-byte slot c ^ (r & 7) (conflict-free ds_read_b128) ----------------
+    const int sw0 = ((0 + fq) ^ (fr & 7)) << 4, sw1 = ((4 + fq) ^ (fr & 7)) << 4;
+    const char* const pa0 = smem + (wm * MH * 16 + fr) * 128 + sw0;
+    const char* const pa1 = smem + (wm * MH * 16 + fr) * 128 + sw1;
+    const char* const pb00 = smem + OB0 + (wn * NI0 * 16 + fr) * 128 + sw0;
+    const char* const pb01 = smem + OB0 + (wn * NI0 * 16 + fr) * 128 + sw1;
+    const char* const pb10 = smem + OB1 + (wn * NI1 * 16 + fr) * 128 + sw0;
+    const char* const pb11 = smem + OB1 + (wn * NI1 * 16 + fr) * 128 + sw1;
+    half8 fa[MH][2], fb0[NI0][2], fb1[NI1 > 0 ? NI1 : 1][2];
+#define PP_READ_A(MIH, PAR)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < MH; ++i) {                                                        \
+        fa[i][0] = *reinterpret_cast<const half8*>(pa0 + (PAR) * STAGE + ((MIH) ? OA1 : OA0) + i * 2048);   \
+        fa[i][1] = *reinterpret_cast<const half8*>(pa1 + (PAR) * STAGE + ((MIH) ? OA1 : OA0) + i * 2048);   \
+    }
+#define PP_READ_B0(PAR)                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < NI0; ++j) {                                                       \
+        fb0[j][0] = *reinterpret_cast<const half8*>(pb00 + (PAR) * STAGE + j * 2048);                       \
+        fb0[j][1] = *reinterpret_cast<const half8*>(pb01 + (PAR) * STAGE + j * 2048);                       \
+    }
+#define PP_READ_B1(PAR)                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < NI1; ++j) {                                                       \
+        fb1[j][0] = *reinterpret_cast<const half8*>(pb10 + (PAR) * STAGE + j * 2048);                       \
+        fb1[j][1] = *reinterpret_cast<const half8*>(pb11 + (PAR) * STAGE + j * 2048);                       \
+    }
+    floatx4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#define PP_MFMA(MIH, FB, NJ, J0)                                                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                        \
+        _Pragma("unroll") for (int i = 0; i < MH; ++i)                                                      \
+            _Pragma("unroll") for (int j = 0; j < (NJ); ++j)                                                \
+                acc[(MIH) * MH + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                     \
+                    FB[j][ks], fa[i][ks], acc[(MIH) * MH + i][(J0) + j], 0, 0, 0);
+#define PP_BAR()                          \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);
+#define PP_WAIT() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+    // phase P (0..7) of a pair of K-tiles: parity P >> 2 is read, the piece six pieces ahead is staged
+#define PP_PHASE(P)                                                                                         \
+    {                                                                                                       \
+        constexpr int par_ = (P) >> 2, ph_ = (P) & 3;                                                       \
+        PP_STAMP(ts_a[ph_])                                                                                 \
+        if (ph_ == 0) { PP_READ_B0(par_); __builtin_amdgcn_sched_barrier(0); PP_READ_A(0, par_); }          \
+        if (ph_ == 1) { PP_READ_B1(par_); }                                                                 \
+        if (ph_ == 2) { PP_READ_A(1, par_); }                                                               \
+        PP_ISSUE(((P) + 6) & 3, (((P) + 6) >> 2) & 1);                                                      \
+        if (ph_ != 3) { PP_WAIT(); }                                                                        \
+        PP_STAMP(ts_b[ph_])                                                                                 \
+        PP_BAR();                                                                                           \
+        if (ph_ == 0) { PP_MFMA(0, fb0, NI0, 0); }                                                          \
+        if (ph_ == 1) { PP_MFMA(0, fb1, NI1, NI0); }                                                        \
+        if (ph_ == 2) { PP_MFMA(1, fb1, NI1, NI0); }                                                        \
+        if (ph_ == 3) { PP_MFMA(1, fb0, NI0, 0); }                                                          \
+        PP_PREP(((P) + 7) & 3);                                                                             \
+        PP_STAMP(ts_d[ph_])                                                                                 \
+        PP_BAR();                                                                                           \
+    }
+
+    // ---- prologue: K-tile 0 and the first half of K-tile 1 (six pieces); the first two must have landed ----------------
+    PP_PREP_A(0); PP_ISSUE(0, 0); PP_PREP(1); PP_ISSUE(1, 0); PP_PREP(2); PP_ISSUE(2, 0); PP_PREP(3); PP_ISSUE(3, 0);
+    PP_PREP(0); PP_ISSUE(0, 1); PP_PREP(1); PP_ISSUE(1, 1);
+    PP_PREP(2);   // phase 0 stages B1 of K-tile 1
+    PP_WAIT();
+    PP_BAR();
+    const bool late = wave >= 4;   // the half that runs one barrier behind
+    if (late) { PP_BAR(); }
+#ifdef FD_PP_STAMPS
+    const unsigned long long ts_loop0 = __builtin_amdgcn_s_memtime();
+#endif
+    int l = 0;
+#pragma clang loop unroll(disable)
+    for (; l + 1 < nkl; l += 2) {
+        PP_PHASE(0) PP_PHASE(1) PP_PHASE(2) PP_PHASE(3)
+        PP_PHASE(4) PP_PHASE(5) PP_PHASE(6) PP_PHASE(7)
+    }
+#ifdef FD_PP_STAMPS
+    const unsigned long long ts_sa[4] = {ts_a[0], ts_a[1], ts_a[2], ts_a[3]}, ts_sb[4] = {ts_b[0], ts_b[1], ts_b[2], ts_b[3]},
+                             ts_sd[4] = {ts_d[0], ts_d[1], ts_d[2], ts_d[3]};   // phases 4..7 of the last full pair
+#endif
+    if (l < nkl) {
+        PP_PHASE(0) PP_PHASE(1) PP_PHASE(2) PP_PHASE(3)
+    }
+    if (!late) { PP_BAR(); }
+#ifdef FD_PP_STAMPS
+    const unsigned long long ts_loop1 = __builtin_amdgcn_s_memtime();
+#endif
+#undef PP_PHASE
+#undef PP_WAIT
+#undef PP_BAR
+#undef PP_MFMA
+#undef PP_READ_A
+#undef PP_READ_B0
+#undef PP_READ_B1
+#undef PP_ISSUE
+#undef PP_ISSUE_A
+#undef PP_ISSUE_B
+#undef PP_PREP
+#undef PP_PREP_A
+#undef PP_PREP_B
+#undef PP_ADVANCE
+#undef PP_GROUP_ROW
+#undef PP_B_ROW
+#undef PP_IS_A2
+
+    // ---- epilogue (the staged pieces past the K range were zero-fill DMAs into ring slots nobody reads; the bias tiles
+    // landed with the first counted wait) --------------------------------------------------------------------------------
+    if constexpr (EPI == 10) {
+        // split-K partial: the raw fp32 tile goes to slab `kslice` of the workspace (k_splitk_finish sums the slabs in a
+        // fixed order and applies the epilogue); every tile is full and N % 4 == 0
+        float* __restrict__ P = g.ws + (size_t)kslice * g.M * g.N + (size_t)(m0 + wm * WTM + fr) * g.N + n0 + wn * WTN + fq * 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) *reinterpret_cast<floatx4*>(P + (size_t)i * 16 * g.N + j * 16) = acc[i][j];
+    } else if constexpr (EPI == 0 || EPI == 7)
+        gemm_epilogue<BM, BN, false, WM_, WN_, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
+                                                         b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr, kslice);
+    else if constexpr (EPI == 8 || EPI == 9) {
+        // the row-statistics exchange buffer reuses the ring: outstanding zero-fill DMAs must have landed before it is written
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        gemm_epilogue_fast<MI, NI, FD_ACT_NONE, EPI == 9, true, false, true, WN_>(
+            g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN),
+            reinterpret_cast<float*>(smem), wm * WTM + fr, wn, m0);
+    } else
+        gemm_epilogue_fast<MI, NI, (EPI == 3 || EPI == 6) ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, true, (EPI == 5 || EPI == 6)>(
+            g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN));
+#ifdef FD_PP_STAMPS
+    if (EPI != 10 && g.ws && lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(g.ws) + ((size_t)blockIdx.x * 8 + wave) * 16;
+        o[0] = ts_start; o[1] = ts_loop0; o[2] = ts_loop1; o[3] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { o[4 + 3 * p] = ts_sa[p]; o[5 + 3 * p] = ts_sb[p]; o[6 + 3 * p] = ts_sd[p]; }
+        o[13] = ts_sa[3]; o[14] = ts_sb[3];
+        o[15] = __builtin_amdgcn_s_memrealtime() - rt_start;   // (replaces phase 3's MFMA-issue stamp)
+    }
+#endif
+#undef PP_STAMP
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int WM_, int WN_, int MI, int NI, bool CONV, int EPI, bool HAS_K2>
+static int pp_launch_k2(GemmArgs& g, int batch, hipStream_t st) {
+    constexpr int BM = WM_ * MI * 16, BN = WN_ * NI * 16;
+    g.tiles_m = g.M / BM;
+    g.tiles_n = g.N / BN;
+    const size_t lds = 2 * (size_t)(BM + BN) * 128 + 4 * BN * sizeof(float);
+    const unsigned long long a_bytes = CONV ? 2ull * (g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi * g.Cin
+                                            : 2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K);
+    const unsigned long long w_bytes = 2ull * ((unsigned long long)(g.N - 1) * g.ldw + g.K + g.K2);
+    static bool configured = false;
+    if (!configured) {
+        FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_pp<WM_, WN_, MI, NI, CONV, EPI, HAS_K2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL((k_gemm_f16_pp<WM_, WN_, MI, NI, CONV, EPI, HAS_K2>), dim3(g.tiles_m * g.tiles_n, g.split_k, batch), dim3(512), lds, st, g,
+                       (unsigned)a_bytes, (unsigned)w_bytes);
+    FD_CHECK_LAUNCH("k_gemm_f16_pp");
+    return FD_OK;
+}
+
+template <int WM_, int WN_, int MI, int NI, bool CONV, int EPI>
+static int pp_launch_k(GemmArgs& g, int batch, hipStream_t st) {
+    // the appended phase exists for the plain / residual / split-K epilogues of convolutions (ResBlock shortcut) and linears
+    // (proj_out folded through FF-out)
+    if constexpr (EPI == 1 || EPI == 2 || EPI == 10 || EPI == 0) {
+        if (g.K2) return pp_launch_k2<WM_, WN_, MI, NI, CONV, EPI, true>(g, batch, st);
+    } else {
+        if (g.K2) {
+            fd_set_error("fd_gemm_f16: the appended A2 phase has no ping-pong kernel with this epilogue");
+            return FD_ESHAPE;
+        }
+    }
+    return pp_launch_k2<WM_, WN_, MI, NI, CONV, EPI, false>(g, batch, st);
+}
+
+// the lean epilogue when its preconditions hold (launch_epi of gemm.hip), the generic one otherwise
+template <int WM_, int WN_, int MI, int NI>
+static int pp_launch(GemmArgs& g, int batch, hipStream_t st) {
+    constexpr int BM = WM_ * MI * 16, BN = WN_ * NI * 16;
+    const bool conv = g.mode == MODE_CONV;
+    if (g.split_k > 1 && (g.N & 3) == 0)
+        return conv ? pp_launch_k<WM_, WN_, MI, NI, true, 10>(g, batch, st) : pp_launch_k<WM_, WN_, MI, NI, false, 10>(g, batch, st);
+    const bool lean = g.split_k == 1 && !g.out_f32 && !g.trans_out && g.bias_lds && (g.ldc & 7) == 0 &&
+                      (!g.bias2 || g.ln_stats || g.rows_per_batch % BM == 0);
+    if (g.ln_stats_out) {
+        if (lean && !conv && (WN_ == 2 || g.N == BN) && g.act == FD_ACT_NONE && !g.ln_stats && !g.bias2) {
+            if (g.res && (g.ldr & 3) == 0) return pp_launch_k<WM_, WN_, MI, NI, false, 9>(g, batch, st);
+            if (!g.res) return pp_launch_k<WM_, WN_, MI, NI, false, 8>(g, batch, st);
+        }
+        fd_set_error("fd_gemm_f16: ln_stats_out on a ping-pong tile needs the lean epilogue of a plain or residual linear GEMM");
+        return FD_ESHAPE;
+    }
+    if (g.ln_stats) {
+        if (lean && !conv && !g.res) {
+            if constexpr (NI % 2 == 0) {
+                if (g.act == FD_ACT_GEGLU) return pp_launch_k<WM_, WN_, MI, NI, false, 6>(g, batch, st);
+            }
+            if (g.act == FD_ACT_NONE) return pp_launch_k<WM_, WN_, MI, NI, false, 5>(g, batch, st);
+        }
+        if (!conv) return pp_launch_k<WM_, WN_, MI, NI, false, 7>(g, batch, st);
+        fd_set_error("fd_gemm_f16: LayerNorm fold on a convolution");
+        return FD_ESHAPE;
+    }
+    if (lean) {
+        if constexpr (NI % 2 == 0) {
+            if (g.act == FD_ACT_GEGLU && !conv) return pp_launch_k<WM_, WN_, MI, NI, false, 3>(g, batch, st);
+        }
+        if (g.act == FD_ACT_NONE && g.res && (g.ldr & 3) == 0)
+            return conv ? pp_launch_k<WM_, WN_, MI, NI, true, 2>(g, batch, st) : pp_launch_k<WM_, WN_, MI, NI, false, 2>(g, batch, st);
+        if (g.act == FD_ACT_NONE && !g.res)
+            return conv ? pp_launch_k<WM_, WN_, MI, NI, true, 1>(g, batch, st) : pp_launch_k<WM_, WN_, MI, NI, false, 1>(g, batch, st);
+    }
+    return conv ? pp_launch_k<WM_, WN_, MI, NI, true, 0>(g, batch, st) : pp_launch_k<WM_, WN_, MI, NI, false, 0>(g, batch, st);
+}
+
+void fd_gemm_pp_tile_shape(int tile, int* bm, int* bn) {
+    switch (tile) {
+        case 30: *bm = 256; *bn = 320; break;   // 2 x 4 waves of 128 x 80
+        case 31: *bm = 256; *bn = 256; break;   // 2 x 4 waves of 128 x 64
+        case 32: *bm = 128; *bn = 320; break;   // 2 x 4 waves of 64 x 80
+        case 33: *bm = 256; *bn = 160; break;   // 4 x 2 waves of 64 x 80
+        default: *bm = *bn = 0; break;
+    }
+}
+
+bool fd_gemm_pp_ok(const GemmArgs& g, int batch, int tile) {
+    int bm, bn;
+    fd_gemm_pp_tile_shape(tile, &bm, &bn);
+    if (!bm) return false;
+    if (g.M % bm != 0 || g.N % bn != 0 || g.K % BK != 0 || g.K2 % BK != 0 || g.trans_out) return false;
+    if (g.act == FD_ACT_GEGLU && (bn / (tile == 33 ? 2 : 4)) % 32 != 0) return false;   // value / gate fragment pairs per wave
+    const unsigned long long a_bytes = g.mode == MODE_CONV ? 2ull * (g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi * g.Cin
+                                                           : 2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K);
+    const unsigned long long w_bytes = 2ull * ((unsigned long long)(g.N - 1) * g.ldw + g.K + g.K2);
+    if (a_bytes >= 0x7ffffff0ull || w_bytes >= 0x7ffffff0ull) return false;
+    if (g.mode == MODE_CONV) {
+        // an 8-row DMA group must be 8 consecutive pixels of one image row; no fused nearest upsample (per-lane x >> 1)
+        if (g.Wo % 8 != 0 || g.up || g.Cin % BK != 0) return false;
+        // the appended phase is staged as the centre tap of a second tensor of the same spatial size
+        if (g.K2 && (g.stride != 1 || g.Ho != g.Hi || g.Wo != g.Wi || g.phase)) return false;
+    }
+    if (g.split_k > 1 && (g.K / BK + g.K2 / BK) / g.split_k < 2) return false;
+    (void)batch;
+    return true;
+}
+
+int fd_gemm_pp_launch(GemmArgs& g, int batch, hipStream_t st, int tile) {
+    switch (tile) {
+        case 30: return pp_launch<2, 4, 8, 5>(g, batch, st);
+        case 31: return pp_launch<2, 4, 8, 4>(g, batch, st);
+        case 32: return pp_launch<2, 4, 4, 5>(g, batch, st);
+        case 33: return pp_launch<4, 2, 4, 5>(g, batch, st);
+        default: fd_set_error("fd_gemm_f16: unknown ping-pong tile %d", tile); return FD_EINVAL;
+    }
+}

@@ -176,7 +176,9 @@ typedef struct fd_gemm_desc {
     int64_t batch_stride_a, batch_stride_w, batch_stride_c, batch_stride_res;
     /* scheduling: tile 0 = auto, 1 = 128x128, 2 = 128x160, 3 = 128x64, 4 = 64x64, 5 = 256x160 and
      * 6 = 256x128 (8 waves), 7/8 = the same with 3 LDS stages, 9 = 128x160 and 10 = 128x128 with
-     * 8 waves, 11 = 128x64 with 8 waves, 12 = 128x160, 13 = 256x160 and 14 = 256x128 with 16 waves; split_k 0 =
+     * 8 waves, 11 = 128x64 with 8 waves, 12 = 128x160, 13 = 256x160 and 14 = 256x128 with 16 waves; 30 = 256x320, 31 = 256x256, 32 = 128x320, 33 = 256x160 on
+     * the deep-pipelined ping-pong loop (csrc/gemm_pp.hip: 8 waves, full tiles and K % 64 == 0 only, FD_ESHAPE otherwise);
+     * split_k 0 =
      * auto (needs `workspace`, fp32 [split_k][M][N]), 1 = off. Results are deterministic for
      * a given (shape, tile, split_k). */
     int32_t tile, split_k;
