@@ -818,6 +818,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs g) {
 static bool g_use_dma = getenv("FD_GEMM_NO_DMA") == nullptr;
 static const int g_vae15 = 1;   // 256x256 tiles on the VAE widths (A/B closed in round 1: +19..33 %)
 static int g_tap_fast = getenv("FD_CONV_TAPFAST") ? atoi(getenv("FD_CONV_TAPFAST")) : 1;   // 1: 256x320 tile, 2: every conv tile
+static int g_pp = getenv("FD_GEMM_PP") ? atoi(getenv("FD_GEMM_PP")) : 1;   // 0: never pick the ping-pong tiles (A/B)
 static int g_bias_lds = getenv("FD_GEMM_BIAS_LDS") ? atoi(getenv("FD_GEMM_BIAS_LDS")) : 1;
 static int g_fast_epi = getenv("FD_GEMM_FAST_EPI") ? atoi(getenv("FD_GEMM_FAST_EPI")) : 1;   // 0: generic epilogue only (A/B)
 // 0 = never, 1 = short-K GEMMs only (default), 2 = always
@@ -1206,6 +1207,44 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         if (eff(t23 * split23) > e_cur + 0.08) {
             best_tile = 23;
             best_split = split23;
+        }
+    }
+    // ---- the deep-pipelined ping-pong tiles (gemm_pp.hip) where they measured faster than every choice above on one box
+    // (tools/ab_pp.py, profiles/r05_ab_pp.txt): stride-1 3x3 convolutions without an appended phase on 256x320 tiles -- split
+    // over K until ~every CU has a workgroup -- or 128x320 tiles (+7..18 %), and the long-K linears of the feed-forward output
+    // (+13..14 %).  Convolutions with the ResBlock shortcut appended (their A2 rows stream from HBM inside a few K-tiles),
+    // GEGLU and the short-K projections stay on the 2-barrier kernels (equal or faster there); FD_GEMM_PP=0 switches the rule off.
+    if (g_pp && g_use_dma && g_fast_epi && g_bias_lds && !geglu && !d->ln_stats_out && !g.ln_stats && batch == 1 && !g.out_f32 &&
+        g.act == FD_ACT_NONE && g.N % 320 == 0 && g.M % 128 == 0 && (g.ldc & 7) == 0 && (!g.res || (g.ldr & 3) == 0) &&
+        (!g.bias2 || g.rows_per_batch % 256 == 0)) {
+        const long long t30 = g.M % 256 == 0 ? (long long)(g.M / 256) * (g.N / 320) : 0, t32 = (long long)(g.M / 128) * (g.N / 320);
+        int tile = 0, split = 1;
+        if (g.mode == MODE_CONV && !g.K2 && !g.phase && nk_all >= 32) {
+            if (t30 >= 200 && fd_round_eff(t30, 256) >= 0.85) {
+                tile = 30;
+            } else if (t30 > 0) {
+                while (t30 * split < 200 && split < 4 && nk_all / (split * 2) >= 24 && g.ws && g.N % 4 == 0 &&
+                       (size_t)(split * 2) * g.M * g.N * 4 <= (size_t)d->workspace_bytes)
+                    split *= 2;
+                if (t30 * split >= 200 && fd_round_eff(t30 * split, 256) >= 0.85) tile = 30;
+                // two K slices of a short K loop lose to whole 128x320 tiles (the slab round trip + finish launch are fixed costs)
+                if (tile == 30 && split == 2 && nk_all < 150 && t32 >= 200 && fd_round_eff(t32, 256) >= 0.85) {
+                    tile = 32;
+                    split = 1;
+                }
+            }
+            if (!tile && t32 >= 200 && fd_round_eff(t32, 256) >= 0.85) tile = 32, split = 1;
+        } else if (g.mode != MODE_CONV && g.K + g.K2 >= 1280) {
+            if (t30 >= 200 && fd_round_eff(t30, 256) >= 0.85) tile = 30;
+            else if (t32 >= 200 && fd_round_eff(t32, 256) >= 0.85) tile = 32;
+        }
+        if (tile) {
+            g.split_k = split;
+            if (fd_gemm_pp_ok(g, batch, tile)) {
+                best_tile = tile;
+                best_split = split;
+            }
+            g.split_k = 1;
         }
     }
     if (d->tile) best_tile = d->tile;
