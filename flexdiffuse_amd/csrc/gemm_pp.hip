@@ -120,8 +120,8 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
                 const int b = m / hw, rem = m - b * hw;
                 const int oy = rem / g.Wo, ox0 = rem - oy * g.Wo;
                 const int y = oy * g.stride - pad_t, x = ox0 * g.stride - pad_l;
-                sA_yx[mi][i] = ((y + 0x4000) << 16) | (x + 0x4000);
-                sA_px[mi][i] = (b * g.Hi + y) * g.Wi + x + pad_l;
+                sA_yx[mi][i] = __builtin_amdgcn_readfirstlane(((y + 0x4000) << 16) | (x + 0x4000));
+                sA_px[mi][i] = __builtin_amdgcn_readfirstlane((b * g.Hi + y) * g.Wi + x + pad_l);
             } else {
                 sA_yx[mi][i] = 0;
                 sA_px[mi][i] = m;
@@ -133,35 +133,52 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
     // ---- K range of this workgroup; the K-tile whose pieces are being staged ------------------------------------------
     const int nkc = g.K / BK;                            // K-tiles of the convolution / GEMM proper
     const int nk_all = nkc + (HAS_K2 ? g.K2 / BK : 0);   // + the appended phase over A2 (a compile-time variant)
-    const int kt_per = (nk_all + g.split_k - 1) / g.split_k;
+    const int kt_per = __builtin_amdgcn_readfirstlane((nk_all + g.split_k - 1) / g.split_k);
     const int kt0 = kslice * kt_per;
     const int nk = min(nk_all, kt0 + kt_per);
     const int nkl = nk - kt0;
-    const int ntaps = CONV ? g.K / g.Cin : 1;
+    const int ntaps = CONV ? __builtin_amdgcn_readfirstlane(g.K / g.Cin) : 1;
     // convolution: K-tiles visit all filter taps of one 64-channel slice before the next slice (the taps re-read the same input
-    // rows, so the re-use distance in the XCD's L2 is one K-tile; 5-9 % faster than (tap, slice) order on this loop)
-    int t_cur = kt0, c_kh = 0, c_kw = 0, c_ci0 = 0;
-    if (CONV && kt0 > 0 && kt0 < nkc) {
-        const int tap = kt0 % ntaps;
-        c_ci0 = (kt0 / ntaps) * BK;
-        c_kh = tap / g.KW;
+    // rows, so the re-use distance in the XCD's L2 is one K-tile; 5-9 % faster than (tap, slice) order on this loop).
+    // (Interleaving the appended K-tiles with the others -- one every nk_all / nk2 positions, so that their HBM rows do not arrive
+    // as one burst at the end -- measured equal on FF-out and 5-15 % SLOWER on the ResBlock convolutions, profiles/r05_ab_pp.txt:
+    // the appended form stays.)
+    // (integer divisions run on the VALU: pin their wave-uniform results back into SGPRs, or the whole offset chain that hangs
+    // off them is moved to VGPRs and every LDS-DMA gets a waterfall loop around its scalar offset)
+#define PP_UNIFORM(X) __builtin_amdgcn_readfirstlane(X)
+    int t_cur = kt0;                              // position of the K-tile being staged
+    int a_idx = HAS_K2 ? max(kt0 - nkc, 0) : 0;   // appended K-tiles before t_cur
+    int m_idx = HAS_K2 ? min(kt0, nkc) : kt0;     // main (convolution / GEMM proper) K-tiles before t_cur
+    int c_kh = 0, c_kw = 0, c_ci0 = 0;     // conv: filter tap / channel slice of main K-tile m_idx
+    if (CONV && m_idx > 0) {
+        const int tap = PP_UNIFORM(m_idx % ntaps);
+        c_ci0 = PP_UNIFORM(m_idx / ntaps) * BK;
+        c_kh = PP_UNIFORM(tap / g.KW);
         c_kw = tap - c_kh * g.KW;
     }
+    // (wave-uniform flags are kept as INTEGERS pinned to SGPRs: a uniform i1 combined with && lives in a lane mask, and its
+    // zero-extension -- `if (flag) ++a; else ++b;` -- is emitted as VALU arithmetic that drags the offsets into VGPRs)
+#define PP_FLAG(COND) __builtin_amdgcn_readfirstlane((COND) ? 1 : 0)
+    int cur_a2 = HAS_K2 ? PP_FLAG(t_cur >= nkc) : 0;   // the K-tile at t_cur is an appended one
+#define PP_IS_A2() (HAS_K2 && cur_a2 != 0)
 #define PP_ADVANCE()                                                                                        \
     {                                                                                                       \
-        ++t_cur;                                                                                            \
+        a_idx += cur_a2;                                                                                    \
+        m_idx += 1 - cur_a2;                                                                                \
         if (CONV) {                                                                                         \
-            const bool wrap_w_ = c_kw + 1 == g.KW;                                                          \
-            const bool wrap_h_ = wrap_w_ && (c_kh + 1) * g.KW == ntaps;                                     \
-            c_kw = wrap_w_ ? 0 : c_kw + 1;                                                                  \
-            c_kh = wrap_h_ ? 0 : (wrap_w_ ? c_kh + 1 : c_kh);                                               \
-            c_ci0 = wrap_h_ ? c_ci0 + BK : c_ci0;                                                           \
+            const int adv_ = 1 - cur_a2;                                                                    \
+            const int wrap_w_ = PP_FLAG(c_kw + adv_ == g.KW);                                               \
+            const int wrap_h_ = PP_FLAG(wrap_w_ != 0 && (c_kh + 1) * g.KW == ntaps);                        \
+            c_kw = wrap_w_ ? 0 : c_kw + adv_;                                                               \
+            c_kh = wrap_h_ ? 0 : c_kh + wrap_w_;                                                            \
+            c_ci0 += wrap_h_ * BK;                                                                          \
         }                                                                                                   \
+        ++t_cur;                                                                                            \
+        if (HAS_K2) cur_a2 = PP_FLAG(t_cur >= nkc);                                                         \
     }
     // The appended phase reads plain rows A2[m][lda2].  For a convolution it is staged as the CENTRE tap of a second NHWC
     // tensor with lda2 channels (same spatial size, stride 1: row m is pixel (b, oy, ox)), so that one address form serves both:
     //   soffset = pixel index * bytes per pixel + K-tile offset,   lane part = rsub * pixel stride + chunk
-#define PP_IS_A2() (HAS_K2 && t_cur >= nkc)
     // The scalar operands of a piece's DMAs are PREPARED one phase ahead, behind that phase's MFMAs (the wave has issued
     // them and would otherwise sit at the barrier while they execute): a LOAD section is then only ds_reads + DMA issue.
     // Measured with the s_memtime stamps (tools/pp_stamps.py): with the address arithmetic inside the LOAD sections the
@@ -174,11 +191,11 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
         int pixb_, asoff_, kh_;                                                                             \
         if (CONV) {                                                                                         \
             pixb_ = a2_ ? g.lda2 * 2 : g.Cin * 2;                                                           \
-            asoff_ = a2_ ? (pad_t * g.Wi * g.lda2 + (t_cur - nkc) * BK) * 2 : ((c_kh * g.Wi + c_kw) * g.Cin + c_ci0) * 2; \
+            asoff_ = a2_ ? (pad_t * g.Wi * g.lda2 + a_idx * BK) * 2 : ((c_kh * g.Wi + c_kw) * g.Cin + c_ci0) * 2; \
             kh_ = a2_ ? pad_t : c_kh;                                                                       \
         } else {                                                                                            \
             pixb_ = a2_ ? g.lda2 * 2 : g.lda * 2;                                                           \
-            asoff_ = (a2_ ? t_cur - nkc : t_cur) * BK * 2;                                                  \
+            asoff_ = (a2_ ? a_idx : m_idx) * BK * 2;                                                        \
             kh_ = 0;                                                                                        \
         }                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < CA; ++i) {                                                    \
@@ -194,8 +211,8 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
 #define PP_PREP_B(NIH)                                                                                      \
     {                                                                                                       \
         const bool a2_ = PP_IS_A2();                                                                        \
-        const int wsoff_ = a2_ ? (g.K + (t_cur - nkc) * BK) * 2                                             \
-                               : (CONV ? ((c_kh * g.KW + c_kw) * g.Cin + c_ci0) * 2 : t_cur * BK * 2);      \
+        const int wsoff_ = a2_ ? (g.K + a_idx * BK) * 2                                                     \
+                               : (CONV ? ((c_kh * g.KW + c_kw) * g.Cin + c_ci0) * 2 : m_idx * BK * 2);      \
         _Pragma("unroll") for (int i = 0; i < ((NIH) ? CB1 : CB0); ++i)                                     \
             pB_soff[i] = PP_B_ROW(NIH, i) * g.ldw * 2 + wsoff_;                                             \
     }
@@ -347,6 +364,8 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
 #undef PP_GROUP_ROW
 #undef PP_B_ROW
 #undef PP_IS_A2
+#undef PP_UNIFORM
+#undef PP_FLAG
 
     // ---- epilogue (the staged pieces past the K range were zero-fill DMAs into ring slots nobody reads; the bias tiles
     // landed with the first counted wait) --------------------------------------------------------------------------------
