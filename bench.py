@@ -213,7 +213,64 @@ def best_kernel_leg(dev):
             'avg_launch_us': us, 'achieved': tflops, 'frac': tflops / MFMA_PEAK_TFLOPS}
 
 
-def devmon_collect(proc, t0: float, t1: float) -> dict:
+GEMM_SOURCES = ('common.h', 'gemm.hip', 'gemm_epilogue.h', 'gemm_pp.hip')
+
+
+def sources_sha() -> str:
+    '''sha256 over the sources of the dominant kernel family (csrc/: the GEMM / implicit-GEMM files + common.h), the key that
+    ties a committed PMC traffic record (profiles/r*_pmc_traffic.json `sources_sha`) to the code it was measured on.'''
+    import hashlib
+    h = hashlib.sha256()
+    for name in GEMM_SOURCES:
+        with open(os.path.join(ROOT, 'flexdiffuse_amd', 'csrc', name), 'rb') as f:
+            h.update(name.encode() + b'\0' + f.read())
+    return h.hexdigest()
+
+
+def pick_traffic_record():
+    '''(hbm bytes per launch of the dominant kernel, description, other kernels, stale flag) from the committed PMC records:
+    rocprofv3 cannot run inside this process, so `roofline.traffic` is a per-launch measurement taken by tools/pmc_traffic_r05.sh.
+    The newest record whose `sources_sha` equals today's sources is used; if none matches, the newest record is reported with
+    `traffic_stale: true` (measured on other code).'''
+    import glob
+    import re
+    recs = []
+    for path in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')):
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+            tj['hbm_bytes'], tj['algorithmic_bytes'], tj['problem']      # noqa: B018 -- required keys
+        except (OSError, KeyError, ValueError):
+            continue
+        m = re.match(r'r(\d+)_', os.path.basename(path))
+        recs.append((int(m.group(1)) if m else 0, os.path.basename(path), tj))
+    if not recs:
+        return None, None, None, True
+    recs.sort(key=lambda r: r[0], reverse=True)
+    try:
+        sha = sources_sha()
+    except OSError:
+        sha = None
+    match = [r for r in recs if sha and r[2].get('sources_sha') == sha]
+    _, name, tj = (match or recs)[0]
+    stale = not match
+    of = (f"{tj['problem']}: {tj['hbm_bytes'] / 1e6:.1f} MB per launch vs {tj['algorithmic_bytes'] / 1e6:.1f} MB algorithmic; "
+          f"per-launch PMC measurement from profiles/{name} ({'measured on OTHER sources: stale' if stale else 'sources_sha matches this tree'}), "
+          'not re-measured by this run')
+    other = {k: {'hbm_bytes': v['hbm_bytes'], 'algorithmic_bytes': v['algorithmic_bytes'],
+                 'over_algorithmic': v.get('traffic_over_algorithmic')}
+             for k, v in tj.get('other_kernels', {}).items()} or None
+    return tj['hbm_bytes'], of, other, stale
+
+
+def _bdf_key(bdf):
+    '''(bus, device, function) of a PCI address in any of the spellings amdsmi / sysfs / torch use.'''
+    import re
+    m = re.search(r'([0-9a-f]{2}):([0-9a-f]{2})\.([0-7])\s*$', str(bdf).strip().lower())
+    return (int(m.group(1), 16), int(m.group(2), 16), int(m.group(3))) if m else None
+
+
+def devmon_collect(proc, t0: float, t1: float, device_bdf=None) -> dict:
     '''Stops the sampler child (tools/devmon.py) and averages its samples inside [t0, t1] -- the timed region.
     Makes "fast box / slow box" a number: the MFMA loops are power-capped, so the sustained gfx clock moves the
     result by a few percent between boxes of one pool.'''
@@ -230,6 +287,10 @@ def devmon_collect(proc, t0: float, t1: float) -> dict:
             pass
         return out
     out['clock_source'] = rec.get('source')
+    # which physical GPU was sampled, and is it the one that was timed (amdsmi / sysfs ignore *_VISIBLE_DEVICES)
+    out['clock_device_bdf'] = rec.get('bdf')
+    if rec.get('bdf') and device_bdf and _bdf_key(rec['bdf']) and _bdf_key(device_bdf):
+        out['clock_device_matches'] = _bdf_key(rec['bdf']) == _bdf_key(device_bdf)
     if rec.get('errors') and not rec.get('samples'):
         out['clock_errors'] = rec['errors'][:2]
     inside = [s for s in rec.get('samples', []) if t0 <= s[0] <= t1]
@@ -474,20 +535,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    launch_note = None
+    # (graph capture happens in the first pass; if it fails on this box FlexPipeline itself falls back to the launch plan
+    # and says so in `graph_fallback`)
     for w in range(args.warmup):
-        if w == 0 and pipe.use_graph:
-            # graph capture happens in the first pass: if it fails on this box, run on the launch plan instead of dying
-            try:
-                one_pass()
-                torch.cuda.synchronize()
-            except Exception as ex:      # noqa: BLE001
-                launch_note = f'HIP-graph capture failed ({type(ex).__name__}: {str(ex)[:200]}); ran on the launch plan'
-                pipe.use_graph, pipe.use_plan, pipe._graphs = False, True, {}
-                torch.cuda.synchronize()
-                one_pass()
-            continue
         one_pass()
+    launch_note = pipe.graph_fallback
     # The heap now holds the models, the tokenizer tables and the recorded launch plans (millions of long-lived
     # objects): a full collection over it is a 50-100 ms host stall, and the collector would schedule one whenever a
     # pass's temporaries push the young generations over their thresholds.  Collect once, then move everything that
@@ -502,7 +554,12 @@ def main():
     sync()
     t1 = time.time()
     elapsed = t1 - t0
-    device_state = devmon_collect(devmon, t0, t1)
+    try:
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        timed_bdf = '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:      # noqa: BLE001 -- older torch builds do not expose the PCI address
+        timed_bdf = None
+    device_state = devmon_collect(devmon, t0, t1, timed_bdf)
     if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64,
                             device=dev if dist.get_backend() == 'nccl' else 'cpu')
@@ -565,22 +622,7 @@ def main():
         # HBM bytes of the dominant kernel (level-0 conv3x3) from its PMC pass: rocprofv3 cannot
         # run inside this process, so the committed per-launch measurement is reported with its
         # source (it is NOT re-measured by this run)
-        traffic, traffic_of, traffic_other = None, None, None
-        for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
-            try:
-                with open(os.path.join(ROOT, 'profiles', name)) as f:
-                    tj = json.load(f)
-                traffic = tj['hbm_bytes']
-                traffic_of = (f"{tj['problem']}: {tj['hbm_bytes'] / 1e6:.1f} MB per launch vs "
-                              f"{tj['algorithmic_bytes'] / 1e6:.1f} MB algorithmic; constant from "
-                              f"profiles/{name} (commit {tj.get('commit', 'n/a')}), not measured in this run")
-                # HBM-side bytes per launch of the other kernels of that PMC set (same source, same caveat)
-                traffic_other = {k: {'hbm_bytes': v['hbm_bytes'], 'algorithmic_bytes': v['algorithmic_bytes'],
-                                     'over_algorithmic': v.get('traffic_over_algorithmic')}
-                                 for k, v in tj.get('other_kernels', {}).items()} or None
-                break
-            except (OSError, KeyError, ValueError):
-                continue
+        traffic, traffic_of, traffic_other, traffic_stale = pick_traffic_record()
         fpi = flops_per_image(args.preset, hw, ddim_evals)
         headline = (args.preset == 'sd15' and hw == 512 and args.ddim_steps == 50 and args.scheduler == 'ddim'
                     and args.guidance == 'linear' and B == 8 and not args.img2img)
@@ -624,6 +666,8 @@ def main():
                 # F(2x2,3x3) convolution 4/9 as well); this is the hardware-side rate of the same launches
                 'executed': executed, 'executed_frac': executed / MFMA_PEAK_TFLOPS,
                 'traffic': traffic, 'traffic_of': traffic_of,
+                # false only when the PMC record was collected on exactly these GEMM sources (sha256 recorded with it)
+                'traffic_stale': traffic_stale,
                 'traffic_other_kernels': traffic_other,
                 # sums over the sampled launches (every EVENT_STRIDE-th of each family) of one
                 # untimed pass, empty-bracket cost subtracted, scaled to the pass

@@ -1214,12 +1214,15 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     // over K until ~every CU has a workgroup -- or 128x320 tiles (+7..18 %), and the long-K linears of the feed-forward output
     // (+13..14 %).  Convolutions with the ResBlock shortcut appended (their A2 rows stream from HBM inside a few K-tiles),
     // GEGLU and the short-K projections stay on the 2-barrier kernels (equal or faster there); FD_GEMM_PP=0 switches the rule off.
-    if (g_pp && g_use_dma && g_fast_epi && g_bias_lds && !geglu && !d->ln_stats_out && !g.ln_stats && batch == 1 && !g.out_f32 &&
+    if (g_pp && g_use_dma && g_fast_epi && g_bias_lds && !geglu && !d->ln_stats_out && !g.ln_stats && (batch == 1 || g.phase) && !g.out_f32 &&
         g.act == FD_ACT_NONE && g.N % 320 == 0 && g.M % 128 == 0 && (g.ldc & 7) == 0 && (!g.res || (g.ldr & 3) == 0) &&
         (!g.bias2 || g.rows_per_batch % 256 == 0)) {
-        const long long t30 = g.M % 256 == 0 ? (long long)(g.M / 256) * (g.N / 320) : 0, t32 = (long long)(g.M / 128) * (g.N / 320);
+        // (the parity-decomposed upsample convolution is four launch slices -- blockIdx.z -- of the same tile grid: no split-K there)
+        const long long t30 = (g.M % 256 == 0 ? (long long)(g.M / 256) * (g.N / 320) : 0) * batch, t32 = (long long)(g.M / 128) * (g.N / 320) * batch;
         int tile = 0, split = 1;
-        if (g.mode == MODE_CONV && !g.K2 && !g.phase && nk_all >= 32) {
+        if (g.mode == MODE_CONV && g.phase) {
+            if (t30 >= 200 && fd_round_eff(t30, 256) >= 0.85 && nk_all >= 32) tile = 30;     // tools/.. rule guard: 168 vs 182 us at 32x32 -> 64x64
+        } else if (g.mode == MODE_CONV && !g.K2 && nk_all >= 32) {
             if (t30 >= 200 && fd_round_eff(t30, 256) >= 0.85) {
                 tile = 30;
             } else if (t30 > 0) {

@@ -553,11 +553,18 @@ def prep_gn_fold(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor
     return GNFold(wg.contiguous().to(dev), biasf.contiguous().to(dev), G, eps, N, C)
 
 
-def gn_fold_supported(B: int, HW: int, N: int) -> bool:
+GN_FOLD_MAX_C, GN_FOLD_MAX_G = 48 * 1024 // (16 * 2), 64   # fd_groupnorm_fold_linear_f16: fp16 [16][C] weight tile <= 48 KiB of LDS; gsum_s[16][64]
+
+
+def gn_fold_supported(B: int, HW: int, N: int, C: Optional[int] = None, G: int = 32) -> bool:
     '''The fold pays where the per-sample weights (B x N x C) are smaller than the activation (B x HW x C) they stand
-    in for, and the consumer GEMM needs whole row tiles per sample.'''
+    in for, and the consumer GEMM needs whole row tiles per sample.  `C` (input channels of the folded layer, default N:
+    the transformer's proj_in is square) and `G` must fit the fold kernel's LDS tiles (C <= 1536, G <= 64): a wider
+    layer falls back to the unfused GroupNorm here instead of failing with FD_ESHAPE inside the forward.'''
     mode = os.environ.get('FD_UNET_GN_FOLD', '1')    # 0: never; 1: where the map is >= 8x wider than the layer; 2: wherever N < HW
-    return mode != '0' and HW % 256 == 0 and B > 1 and (N * 8 <= HW if mode == '1' else N < HW)
+    C = N if C is None else C
+    return (mode != '0' and HW % 256 == 0 and B > 1 and (N * 8 <= HW if mode == '1' else N < HW)
+            and C <= GN_FOLD_MAX_C and G <= GN_FOLD_MAX_G)
 
 
 def gn_fold_linear(x: Act, gf: GNFold) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -7,10 +7,11 @@ Device loop: for `SimpleGuide` + DDIM the whole step is  UNet(NHWC fp16, CFG bat
 inside the layout kernel) -> fused CFG + DDIM update on the fp32 latents  with no host
 round trip; any other guide object goes through the reference protocol
 (`guide.noise_pred` + `scheduler.step`) unchanged.  The UNet forward of the fused loop is
-replayed from a LAUNCH PLAN (`use_plan`, default): its ~430 C-ABI launches are recorded once
-per (shape, context) and re-issued each step by one library call -- the same eager launches
-in the same order, without the Python front's per-op work, so the host stays far ahead of
-the device whatever the host CPU (8 ranks on one node share its cores).
+replayed from a captured HIP GRAPH (`use_graph`, default: one host call per denoising step;
+the mode `bench.py` measures) and, if capture fails on a box, from a LAUNCH PLAN (`use_plan`):
+its ~310 C-ABI launches recorded once per (shape, context) and re-issued each step by one
+library call -- the same eager launches in the same order, without the Python front's per-op
+work.  Same kernels, same order, bit-identical results in all three modes.
 
 Deliberate differences: E6 initial noise is drawn on the generator's own
 device -- pass a CPU generator for results independent of the GPU count; E8 `init_image`
@@ -81,14 +82,16 @@ class FlexPipeline():
         self.device = getattr(unet, 'device', torch.device('cuda'))
         self.last_latents: Optional[torch.Tensor] = None
         self.last_images: Optional[torch.Tensor] = None
-        # opt-in: replay the UNet forward of the fused loop from a captured HIP graph (no
-        # per-kernel host launch work).  Measured on one MI355X the loop is not launch-bound
-        # (graph 7.00 vs eager 7.14 images/s on the same box), so eager launches stay the default.
-        self.use_graph = False
+        # default: replay the UNet forward of the fused loop from a captured HIP graph -- one host call per step, so a
+        # host stall cannot starve the device; 0.3-0.6 % faster per forward than the launch plan on the 311-launch
+        # forward (profiles/r04_session_ab.txt sec. 2).  If capture fails, `_unet_eps` switches this pipeline to the
+        # launch plan (`graph_fallback` says why).
+        self.use_graph = True
+        self.graph_fallback: Optional[str] = None
         self._graphs = {}
         self._lat_bufs = {}
-        # default: replay the UNet forward of the fused loop from its recorded launch plan
-        # (hip.Plan): identical kernels / order / results to the eager front, ~1/5 of its host time
+        # the launch plan (hip.Plan): identical kernels / order / results to the eager front, ~1/5 of its host time;
+        # used when use_graph is off or fell back
         self.use_plan = True
         self._plans = {}
         # opt-in (bench.py, Runner(pause_gc=True)): keep the cyclic GC off across the denoising loop.
@@ -97,13 +100,14 @@ class FlexPipeline():
 
     @classmethod
     def from_pretrained(cls, sd_dir, clip_dir=None, tokenizer_dir=None, preset: str = 'sd15',
-                        device='cuda', **_):
+                        device='cuda', scheduler=None, text_cleanup: str = 'basic', **_):
         '''Local files only (there is no hub access): `sd_dir` is a diffusers-layout checkpoint
         directory (unet/, vae/, optionally tokenizer/), `clip_dir` a CLIPModel directory -- what the
         reference's `Runner.__init__` obtains from the hub (utils.py:59-71).  See
         `flexdiffuse_amd.build.from_directories`.'''
         from .. import build
-        return build.from_directories(sd_dir, clip_dir, tokenizer_dir, preset=preset, device=device)[0]
+        return build.from_directories(sd_dir, clip_dir, tokenizer_dir, preset=preset, device=device,
+                                      scheduler=scheduler, text_cleanup=text_cleanup)[0]
 
     def to(self, device):
         self.device = torch.device(device)
@@ -171,11 +175,18 @@ class FlexPipeline():
             t_static.fill_(float(t))
             self.unet.forward_nhwc(latents, t_static, ctx, rep=rep)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: only THIS thread's calls are checked against the capture -- a process-group watchdog thread
-            # (RCCL, N > 1) polling its events must not invalidate it
-            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                eps = self.unet.forward_nhwc(latents, t_static, ctx, rep=rep)
+            try:
+                graph = torch.cuda.CUDAGraph()
+                # thread_local: only THIS thread's calls are checked against the capture -- a process-group watchdog
+                # thread (RCCL, N > 1) polling its events must not invalidate it
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    eps = self.unet.forward_nhwc(latents, t_static, ctx, rep=rep)
+            except Exception as ex:      # noqa: BLE001 -- capture is an optimisation: never fail the request over it
+                self.graph_fallback = f'HIP-graph capture failed ({type(ex).__name__}: {str(ex)[:200]}); running on the launch plan'
+                warnings.warn(self.graph_fallback, RuntimeWarning)
+                self.use_graph, self.use_plan, self._graphs = False, True, {}
+                torch.cuda.synchronize()
+                return self._unet_eps_plan(latents, t, ctx, rep)
             entry = (graph, t_static, eps, ctx)
             self._graphs = {key: entry}          # keep one graph (its pool holds GBs)
         graph, t_static, eps, ctx_ref = entry

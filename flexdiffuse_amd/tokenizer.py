@@ -78,19 +78,21 @@ class CLIPBPETokenizer():
     `[BOS] ids [EOS]`, truncated so that EOS survives, padded with `pad_token` (the EOS token
     for SD1.x; "!" = id 0 for the SD2.x tokenizer).
 
-    Which Hugging Face path this mirrors.  `text_cleanup='fast'` (default) is the pipeline of
+    Which Hugging Face path this mirrors.  `text_cleanup='fast'` (default of this class) is the pipeline of
     the `tokenizers`-backed CLIPTokenizer (`CLIPTokenizerFast`; the only CLIPTokenizer of
-    transformers >= 5): normalizers NFC -> `\\s+` -> " " -> lower case, then the piece pattern
-    -- checked id-for-id against the installed transformers in tests/test_tokenizer.py, CJK
-    and control characters included.  The reference pins transformers 4.21.1 and calls the SLOW
-    `CLIPTokenizer` (utils.py:61-63) without `ftfy` in its requirements; that class then runs
-    BERT's BasicTokenizer first, which additionally DROPS control / NUL / U+FFFD characters and
-    puts spaces around every CJK ideograph (so a CJK run becomes one piece per character).
-    `text_cleanup='basic'` restates those two clean-ups (from the published BasicTokenizer
-    algorithm; transformers 4.21.1 is not installed, so only known answers pin it).  The two
-    modes agree on every prompt without such characters.  Needs the third-party `regex`
-    module (Unicode property classes in the piece pattern), as transformers' own slow
-    tokenizer does.'''
+    transformers >= 5, and what the slow class does when `ftfy` is installed): normalizers NFC -> `\\s+` -> " "
+    -> lower case, then the piece pattern -- checked id-for-id against the installed transformers in
+    tests/test_tokenizer.py, CJK and control characters included.
+    `text_cleanup='basic'` is the mode that matches the REFERENCE'S PINNED STACK: transformers 4.21.1 calls the
+    SLOW `CLIPTokenizer` (utils.py:61-63) and `ftfy` is not in its requirements, so the text first goes through
+    BERT's BasicTokenizer -- the full algorithm, restated here from the published source: control / NUL / U+FFFD
+    characters dropped, spaces around every CJK ideograph, lower-casing, NFD + removal of combining marks
+    (ACCENTS STRIPPED: "café" -> "cafe"), and EVERY punctuation character split off as its own token
+    ("it's" -> it ' s, so the clitic pieces of the pattern never fire).  The two modes therefore DIFFER on prompts
+    with apostrophes, accents or punctuation inside words; they agree on plain lower-ASCII words and spaces.
+    `build.from_directories` / `Runner` / `FlexPipeline.from_pretrained` default to 'basic' for that reason.
+    (transformers 4.21.1 is not installed, so only known answers pin the 'basic' mode.)  Needs the third-party
+    `regex` module (Unicode property classes in the piece pattern), as transformers' own slow tokenizer does.'''
 
     BOS, EOS = '<|startoftext|>', '<|endoftext|>'
 

@@ -278,7 +278,7 @@ class UNet2DConditionModel():
         samples.'''
         B, HW, C = x.B, x.HW, a.C
         d = C // a.heads
-        gn_fold = ops.gn_fold_supported(B, HW, C)
+        gn_fold = ops.gn_fold_supported(B, HW, C, C, self.G)
         h = None if gn_fold else ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False)
         # LayerNorm fold: the GEMM that PRODUCES a LayerNorm input also writes its row statistics where one
         # tile spans the row (C == 320: the 64x64 level); elsewhere one read-only statistics pass

@@ -63,12 +63,15 @@ class Runner():
     def __init__(self, local: bool = True, device: str = 'cuda', *, sd_dir: Optional[str] = None,
                  clip_dir: Optional[str] = None, tokenizer_dir: Optional[str] = None,
                  state_dicts: Optional[Dict[str, dict]] = None, preset: str = 'sd15', seed_weights: int = 0,
-                 freeze_gc: bool = False, pause_gc: bool = False) -> None:
+                 freeze_gc: bool = False, pause_gc: bool = False, scheduler=None, text_cleanup: str = 'basic') -> None:
         '''`Runner(local=True, device='cuda')` as the reference constructs it (utils.py:54-76); the hub
         ids the reference hard-codes (utils.py:24-25) become local directories:
           sd_dir        diffusers-layout checkpoint (unet/, vae/, tokenizer/) -- env FD_SD_DIR
           clip_dir      CLIPModel directory                                    -- env FD_CLIP_DIR
           tokenizer_dir vocab.json + merges.txt; default `sd_dir`/tokenizer     -- env FD_TOKENIZER_DIR
+        The scheduler is the checkpoint's own (`sd_dir`/scheduler/scheduler_config.json: PNDM/PLMS for SD-v1-4, as the
+        reference's `sd.scheduler`, utils.py:70) unless `scheduler=` overrides it; `text_cleanup='basic'` is the
+        tokenization of the reference's pinned slow CLIPTokenizer ('fast': CLIPTokenizerFast).
         `local=False` (the reference's --dl) cannot be served: there is no hub access here.
         Without directories: `state_dicts` (fp32 CPU tensors with HF key names) or seeded synthetic
         weights of `preset` with the synthetic tokenizer.
@@ -85,12 +88,12 @@ class Runner():
             if not (sd_dir and clip_dir):
                 raise ValueError('Runner needs both sd_dir and clip_dir (utils.py:24-25: two checkpoints)')
             self.pipe, clip, tok = build.from_directories(sd_dir, clip_dir, tokenizer_dir, preset=preset,
-                                                          device=device)
+                                                          device=device, scheduler=scheduler, text_cleanup=text_cleanup)
         else:
             if state_dicts is None:
                 state_dicts = build.synthetic_state_dicts(preset, seed=seed_weights)
-            tok = build.load_tokenizer(tokenizer_dir) if tokenizer_dir else None
-            self.pipe, clip, tok = build.build_models(state_dicts, preset, device, tokenizer=tok)
+            tok = build.load_tokenizer(tokenizer_dir, text_cleanup) if tokenizer_dir else None
+            self.pipe, clip, tok = build.build_models(state_dicts, preset, device, tokenizer=tok, scheduler=scheduler)
         self.pipe.pause_gc = pause_gc
         self.device = device
         self.encoder = CLIPEncoder(clip, self.pipe.tokenizer)     # utils.py:73-74

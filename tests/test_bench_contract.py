@@ -1,5 +1,6 @@
-'''The bench line contract (driver + judge read these fields) checked on the committed round-4 line profiles/r04_bench.json -- the output
-of the full default `python bench.py` on an MI355X -- and on bench.py's argument defaults.  CPU only.'''
+'''The bench line contract (driver + judge read these fields) checked on the newest committed full line profiles/rNN_bench.json -- the output
+of the full default `python bench.py` on an MI355X --, on bench.py's argument defaults and on the source-binding of the PMC traffic record.
+CPU only; the live line is checked by tests/test_gpu_dist.py with the same checker (tests/bench_contract.py).'''
 import json
 import os
 import subprocess
@@ -9,30 +10,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, 'profiles', 'r04_bench.json')) as f:
+    '''The newest committed full default line (profiles/rNN_bench.json).  The same checker runs on a LIVE line in
+    tests/test_gpu_dist.py::test_live_mini_bench_line_meets_the_contract.'''
+    import glob
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bench_contract import check_bench_line
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_bench.json')))
+    assert paths, 'no committed bench line under profiles/'
+    with open(paths[-1]) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
-    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
-              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
-        assert k in d, k
-    assert d['unit'] == 'images/sec' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
-    assert d['dtype'] == 'fp16' and d['data'] == 'synthetic' and d['n_gpus'] == 1
-    assert 'BASELINE configs[1]' in d['config']['workload'] and 'model' not in d['config']
-    # value = images of all timed passes / the timed seconds
-    assert abs(d['value'] - d['config']['images_per_step'] * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
-    r = d['roofline']
-    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'executed', 'executed_frac'):
-        assert k in r, k
-    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 2516.6
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['executed_frac'] <= r['frac'] < 1
-    assert r['families_fit_in_step'] and r['families_ms_per_pass'] <= d['ms_per_step']
-    c = d['cpu_baseline']
-    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
-        assert k in c, k
-    assert c['kind'] == 'port' and c['cores'] >= 1 and 0 < c['value'] < d['value']
-    dev = d['device']
-    assert dev['cu_count'] == 256 and 1000 < dev['avg_sclk_mhz'] < 2500 and 200 < dev['avg_power_w'] < 2000
-    assert d['parity']['c1']['psnr_db'] >= 40 and d['parity']['c2']['psnr_db'] >= 40
-    assert d['parity']['c1']['timesteps_equal'] and d['parity']['c2']['timesteps_equal']
+    check_bench_line(d, full=True)
+
+
+def test_traffic_record_is_tied_to_the_sources():
+    '''bench.py reports `roofline.traffic` from the newest profiles/r*_pmc_traffic.json whose `sources_sha` equals the sha256 of
+    today's GEMM sources, and says `traffic_stale: true` otherwise.'''
+    sys.path.insert(0, ROOT)
+    argv, sys.argv = sys.argv, ['bench.py']
+    try:
+        import bench
+    finally:
+        sys.argv = argv
+    sha = bench.sources_sha()
+    assert len(sha) == 64 and sha == bench.sources_sha()
+    traffic, of, other, stale = bench.pick_traffic_record()
+    assert traffic and traffic > 50e6 and isinstance(stale, bool) and ('stale' in of) == stale
+    import glob
+    matching = [p for p in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')) if json.load(open(p)).get('sources_sha') == sha]
+    assert stale == (not matching)
 
 
 def test_bench_defaults_finish_in_minutes_and_help_parses():

@@ -95,6 +95,17 @@ def test_bench_launches_eight_ranks():
     assert line['host_margin']['launch'] == 'graph' and line['config']['launch_note'] is None
 
 
+def test_live_mini_bench_line_meets_the_contract():
+    '''the contract is checked on a line bench.py prints HERE (mini preset, default launch mode), not only on a committed
+    artifact: every field the driver and the judge read, device-state assertions conditional on the sampler having a source.'''
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bench_contract import check_bench_line
+    line = _bench(MINI)
+    check_bench_line(line, full=False)
+    assert line['host_margin']['launch'] == 'graph' and line['config']['launch_note'] is None
+    assert 'traffic_stale' in line['roofline']
+
+
 def test_bench_single_rank_rccl_line():
     '''N = 1 through the RCCL path (FD_FORCE_DIST=1): same line shape, rccl_ranks 1, and the
     roofline / all_gather objects are present and self-consistent.'''

@@ -250,7 +250,9 @@ def attn_ref(q, k, v, heads, causal=False):
                                                   (2048, 1024, 2, 40, False), (2200, 1100, 1, 48, False),
                                                   (2048, 2048, 1, 40, True),
                                                   # long query rows x short text context: two query blocks per wave
-                                                  (4096, 77, 8, 40, False), (2100, 64, 2, 48, False), (2048, 200, 2, 40, False)])
+                                                  (4096, 77, 8, 40, False), (2100, 64, 2, 48, False), (2048, 200, 2, 40, False),
+                                                  # the exact level-0 self-attention shape of the SD1.5 UNet (64x64 latents, 8 heads x 40)
+                                                  (4096, 4096, 8, 40, False)])
 def test_attention(dev, Nq, Nk, heads, d, causal):
     from flexdiffuse_amd import ops
     B, C = 2, heads * d
@@ -274,7 +276,9 @@ def test_attention(dev, Nq, Nk, heads, d, causal):
                                                   # >= 2048 queries x >= 1024 keys: two query blocks per wave
                                                   (2048, 1024, 2, 40, False), (4096, 4096, 1, 40, False),
                                                   (2100, 1030, 2, 48, False), (2048, 1024, 1, 32, True),
-                                                  (4096, 77, 8, 40, False), (2100, 64, 2, 48, False), (2304, 200, 2, 40, False)])
+                                                  (4096, 77, 8, 40, False), (2100, 64, 2, 48, False), (2304, 200, 2, 40, False),
+                                                  # the exact level-0 self-attention launch (k_attention_w8q2<64,3,true,true>: 12 % of the pass)
+                                                  (4096, 4096, 8, 40, False)])
 def test_attention_prescaled_q(dev, Nq, Nk, heads, d, causal):
     '''q_prescaled: Q carries head_dim^-0.5 * log2(e); the kernel feeds the running max into
     the QK^T MFMA accumulator and (head_dim <= 40) takes the denominator from the PV MFMA.

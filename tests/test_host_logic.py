@@ -120,7 +120,7 @@ def test_scheduler_config_and_pipeline_constructor_rewrite():
         assert pipe.scheduler.config.get('steps_offset', 0) == want_off
         pipe.scheduler.set_timesteps(10)
         assert int(pipe.scheduler.timesteps[-1]) == want_off
-    assert pipe.pause_gc is False and pipe.use_plan is True
+    assert pipe.pause_gc is False and pipe.use_plan is True and pipe.use_graph is True
 
 
 def test_runner_constructor_refusals_and_from_directories(tmp_path):
@@ -145,6 +145,36 @@ def test_runner_constructor_refusals_and_from_directories(tmp_path):
     assert build.configs('mini_bpe')[2].text.vocab_size == 1024
 
 
+def test_scheduler_comes_from_the_checkpoint_directory(tmp_path):
+    '''the reference hands the checkpoint's own scheduler to its pipeline (utils.py:70 `sd.scheduler`; SD-v1-4 ships
+    PNDM / PLMS), so `build.load_scheduler` maps scheduler/scheduler_config.json to this package's classes with the file's
+    parameters, returns None without the folder and refuses classes it does not provide.'''
+    import json
+    import os
+    from flexdiffuse_amd import build
+    assert build.load_scheduler(str(tmp_path)) is None
+    os.makedirs(tmp_path / 'scheduler')
+    cfg = tmp_path / 'scheduler' / 'scheduler_config.json'
+    cfg.write_text(json.dumps({'_class_name': 'PNDMScheduler', '_diffusers_version': '0.2.2', 'beta_end': 0.012,
+                               'beta_schedule': 'scaled_linear', 'beta_start': 0.00085, 'num_train_timesteps': 1000,
+                               'skip_prk_steps': True}))
+    s = build.load_scheduler(str(tmp_path))
+    assert type(s).__name__ == 'PNDMScheduler' and s.config['skip_prk_steps'] is True and s.config['beta_end'] == 0.012
+    s.set_timesteps(50)
+    assert len(s.timesteps) == 51                      # PLMS: one extra UNet evaluation
+    cfg.write_text(json.dumps({'_class_name': 'DDIMScheduler', 'beta_start': 0.00085, 'beta_end': 0.012,
+                               'beta_schedule': 'scaled_linear', 'num_train_timesteps': 1000, 'clip_sample': False,
+                               'set_alpha_to_one': False, 'steps_offset': 1}))
+    s = build.load_scheduler(str(tmp_path))
+    assert type(s).__name__ == 'DDIMScheduler' and s.config['steps_offset'] == 1
+    cfg.write_text(json.dumps({'_class_name': 'LMSDiscreteScheduler', 'beta_start': 0.00085, 'beta_end': 0.012,
+                               'beta_schedule': 'scaled_linear', 'num_train_timesteps': 1000}))
+    assert type(build.load_scheduler(str(tmp_path))).__name__ == 'LMSDiscreteScheduler'
+    cfg.write_text(json.dumps({'_class_name': 'EulerDiscreteScheduler'}))
+    with pytest.raises(NotImplementedError):
+        build.load_scheduler(str(tmp_path))
+
+
 def test_devmon_and_bench_clock_fields_without_a_gpu():
     '''tools/devmon.py never touches HIP and degrades to "no source" where no AMD GPU is visible; bench.devmon_collect
     turns whatever the sampler child printed into the `device.*` fields (None when there is nothing).'''
@@ -163,9 +193,40 @@ def test_devmon_and_bench_clock_fields_without_a_gpu():
     t0 = time.time()
     fake = subprocess.Popen([sys.executable, '-c',
                              'import sys, json, time; sys.stdin.read(); t = %r; '
-                             'print(json.dumps({"source": "fake", "errors": [], "samples": '
+                             'print(json.dumps({"source": "fake", "errors": [], "bdf": "0000:C5:00.0", "samples": '
                              '[[t + 0.1, 2000.0, 1000.0, 1900.0], [t + 0.2, 2100.0, 1100.0, 1900.0], [t + 9.0, 50.0, 90.0, 900.0]]}))' % t0],
                             stdin=subprocess.PIPE, stdout=subprocess.PIPE)
-    out = bench.devmon_collect(fake, t0, t0 + 1.0)
+    out = bench.devmon_collect(fake, t0, t0 + 1.0, '0000:c5:00.0')
     assert out['clock_source'] == 'fake' and out['clock_samples'] == 2
     assert out['avg_sclk_mhz'] == 2050.0 and out['avg_power_w'] == 1050.0 and out['max_sclk_mhz'] == 2100.0
+    # the sampler says WHICH physical GPU it read, and the line says whether that is the timed one
+    assert out['clock_device_bdf'] == '0000:C5:00.0' and out['clock_device_matches'] is True
+    assert bench._bdf_key('c5:00.0') == bench._bdf_key('0000:C5:00.0') != bench._bdf_key('0000:c6:00.0')
+    # amdsmi / sysfs ordinals are physical: the runtime's ordinal goes through ROCR_ then HIP_VISIBLE_DEVICES
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import devmon
+    keep = {k: os.environ.pop(k, None) for k in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')}
+    try:
+        assert devmon.physical_index(1, 8) == 1
+        os.environ['ROCR_VISIBLE_DEVICES'] = '4,5,6,7'
+        assert devmon.physical_index(1, 8) == 5
+        os.environ['HIP_VISIBLE_DEVICES'] = '2,3'
+        assert devmon.physical_index(0, 8) == 6 and devmon.physical_index(1, 8) == 7
+        os.environ['HIP_VISIBLE_DEVICES'] = 'GPU-deadbeef'
+        assert devmon.physical_index(0, 8) == 0          # cannot be mapped here: the BDF comparison is the check
+    finally:
+        for k, v in keep.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def test_gn_fold_predicate_knows_the_kernel_limits():
+    '''fd_groupnorm_fold_linear_f16 keeps a 16 x C fp16 tile in <= 48 KiB of LDS and 64 group slots; the host predicate must
+    send wider layers to the unfused GroupNorm instead of letting the forward hit FD_ESHAPE.'''
+    from flexdiffuse_amd import ops
+    assert ops.gn_fold_supported(16, 4096, 320) and ops.gn_fold_supported(16, 4096, 320, 320, 32)
+    assert ops.gn_fold_supported(2, 16384, 1536, 1536, 32)
+    assert not ops.gn_fold_supported(2, 65536, 2048, 2048, 32)       # C too wide for the weight tile
+    assert not ops.gn_fold_supported(16, 4096, 320, 320, 128)        # more groups than slots
+    assert not ops.gn_fold_supported(1, 4096, 320)                   # B == 1: nothing shared

@@ -36,8 +36,13 @@ class SmiSource():
         import amdsmi
         self.smi = amdsmi
         amdsmi.amdsmi_init()
-        self.h = amdsmi.amdsmi_get_processor_handles()[index]
+        handles = amdsmi.amdsmi_get_processor_handles()
+        self.h = handles[physical_index(index, len(handles))]
         self.read()                                        # raises if the call is not permitted
+        try:
+            self.bdf = str(amdsmi.amdsmi_get_gpu_device_bdf(self.h)).lower()
+        except Exception:                                  # noqa: BLE001
+            self.bdf = None
 
     def read(self):
         m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
@@ -63,7 +68,8 @@ class SysfsSource():
                     cards.append(d)
             except OSError:
                 pass
-        self.dev = cards[index]
+        self.dev = cards[physical_index(index, len(cards))]
+        self.bdf = os.path.basename(os.path.realpath(self.dev)).lower()
         hw = glob.glob(os.path.join(self.dev, 'hwmon', 'hwmon*'))
         self.power = None
         for h in hw:
@@ -89,6 +95,24 @@ class SysfsSource():
         except OSError:
             pass
         return sclk, (power / 1e6 if power is not None else None), mclk
+
+
+def physical_index(index, n_all):
+    '''amdsmi and sysfs enumerate EVERY GPU of the machine; the bench process numbers the ones its runtime shows it.  Translate
+    the runtime's ordinal through ROCR_VISIBLE_DEVICES (applied first) and HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (an index
+    into what ROCR left).  Entries that are not plain integers (UUIDs) cannot be mapped here: the ordinal is used as is and the
+    caller compares the sampled device's PCI address with the one the runtime reports (bench.py `clock_device_matches`).'''
+    phys = list(range(n_all))
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES' if 'HIP_VISIBLE_DEVICES' in os.environ else 'CUDA_VISIBLE_DEVICES'):
+        val = os.environ.get(var)
+        if val is None or val.strip() == '':
+            continue
+        try:
+            sel = [int(v) for v in val.split(',') if v.strip() != '']
+            phys = [phys[i] for i in sel if 0 <= i < len(phys)]
+        except ValueError:
+            return index
+    return phys[index] if 0 <= index < len(phys) else index
 
 
 def open_source(index=0):
@@ -126,7 +150,7 @@ def main():
         r, _, _ = select.select([sys.stdin], [], [], period)
         if r and not sys.stdin.readline():
             break
-    print(json.dumps({'source': src.name, 'errors': errs[:3], 'samples': samples}))
+    print(json.dumps({'source': src.name, 'errors': errs[:3], 'bdf': getattr(src, 'bdf', None), 'samples': samples}))
 
 
 if __name__ == '__main__':

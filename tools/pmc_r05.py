@@ -21,4 +21,15 @@ for tile, split in arms:
     for _ in range(3):
         ops.gemm(a, lw, a2=a2, residual=res)
 ops.FORCE_TILE, ops.FORCE_SPLIT = 0, 0
+if len(sys.argv) > 2 and sys.argv[2] == 'all':     # the other big kernels of the forward, through the rule
+    st = ops.ln_row_stats(a[:, :320].contiguous())
+    gw = ops.prep_linear_ln(torch.randn((2560, 320), generator=g) * 320 ** -0.5, torch.randn(2560, generator=g), torch.ones(320), torch.zeros(320), dev, geglu=True)
+    a320 = a[:, :320].contiguous()
+    for _ in range(3):
+        ops.gemm(a320, gw, act=ops.ACT_GEGLU, ln_stats=st)
+    for (Bc, Hc, Cc) in ((16, 16, 1280), (16, 8, 1280)):
+        xc = ops.Act((torch.randn((Bc * Hc * Hc, Cc), generator=g) * 0.7).half().to(dev), Bc, Hc, Hc)
+        wc = ops.prep_conv(torch.randn((Cc, Cc, 3, 3), generator=g) * (9 * Cc) ** -0.5, torch.randn(Cc, generator=g), dev)
+        for _ in range(3):
+            ops.conv2d(xc, wc)
 torch.cuda.synchronize()

@@ -6,6 +6,7 @@ library's own choice.
 Outputs are overwritten in place (nothing reads them); launches the library refuses for a candidate are skipped.'''
 import sys, os, ctypes, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from flexdiffuse_amd import hip, ops, build
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
@@ -13,46 +14,9 @@ PRESET = args[0] if len(args) > 0 else 'sd15'
 LAT = int(args[1]) if len(args) > 1 else 64
 B = int(args[2]) if len(args) > 2 else 8
 dev = torch.device('cuda:0')
-rec = collections.OrderedDict()
-keep = []
-orig_call, orig_empty = hip.call, ops._empty
-
-
-def spy(name, *a):
-    if name == 'fd_gemm_f16':
-        d = a[0]._obj
-        key = (d.M, d.N, d.K, d.K2, d.conv, d.in_h, d.in_w, d.in_c, d.kh, d.stride, d.upsample2x, d.act, d.trans_out, d.batch,
-               d.out_f32, bool(d.residual), bool(d.bias2), bool(d.ln_stats), bool(d.ln_stats_out), d.lda, d.ldc)
-        if key not in rec:
-            c = ops.fd_gemm_desc()
-            ctypes.memmove(ctypes.byref(c), ctypes.byref(d), ctypes.sizeof(d))
-            rec[key] = [c, 0]
-        rec[key][1] += 1
-    return orig_call(name, *a)
-
-
-def keep_empty(*a, **k):
-    t = orig_empty(*a, **k)
-    keep.append(t)
-    return t
-
-
-hip.call = spy; ops.hip.call = spy; ops._empty = keep_empty
-te = torch.empty
-torch.empty = lambda *a, **k: (keep.append(te(*a, **k)) or keep[-1])
-sds = build.synthetic_state_dicts(PRESET, seed=0, parts=('unet', 'vae'))
-ucfg, vcfg, _ = build.configs(PRESET)
-from flexdiffuse_amd.unet import UNet2DConditionModel
-from flexdiffuse_amd.vae import AutoencoderKL
-unet = UNet2DConditionModel(sds['unet'], ucfg, dev)
-x = torch.randn((B, 4, LAT, LAT), device=dev); ctx = torch.randn((2 * B, 77, ucfg.cross_attention_dim), device=dev).half()
-keep += [x, ctx]
-unet.forward_nhwc(x, 500, ctx, rep=2)
-if '--no-vae' not in sys.argv:
-    vae = AutoencoderKL(sds['vae'], vcfg, device=dev, encoder=False)
-    vae.decode_nhwc(x)
-torch.cuda.synchronize()
-hip.call = orig_call; ops.hip.call = orig_call; ops._empty = orig_empty; torch.empty = te
+import gemm_recorder
+rec, keep = gemm_recorder.record(PRESET, LAT, B, vae='--no-vae' not in sys.argv, dev=dev)
+orig_call = hip.call
 print(f'{PRESET} latent {LAT} batch {B}: unique launches {len(rec)}', flush=True)
 
 
@@ -76,10 +40,10 @@ for key, (d, cnt) in rec.items():
         orig_call('fd_gemm_f16', ctypes.byref(d), st)
     t_auto = timeit(lambda: run(0, 0))
     row = {}
-    for tile in (1, 2, 3, 4, 6, 9, 10, 11, 12, 13, 14, 15, 16, 20, 23):
+    for tile in (1, 2, 3, 4, 6, 9, 10, 11, 12, 13, 14, 15, 16, 20, 23, 30, 31, 32, 33):
         if act == 4 and tile in (2, 5, 7, 9, 12, 13, 16, 20, 23):
             continue
-        if (tile == 15 and N % 256) or (tile == 16 and N % 320) or (tile == 23 and (M % 288 or N % 160)):
+        if (tile == 15 and N % 256) or (tile == 16 and N % 320) or (tile == 23 and (M % 288 or N % 160)) or (tile >= 30 and (lno or trans)):
             continue
         for sk in (1, 2, 4, 8, 16):
             if sk > 1 and (act == 4 or batch > 1 or lnf or lno or K2 or ((K + K2) // 64) // sk < 4 or sk * M * N * 4 > d.workspace_bytes):
