@@ -611,6 +611,13 @@ def main():
         one_pass(time_gather=True)       # every rank takes part in the extra pass's all-gather
         torch.cuda.synchronize()
 
+    import resource
+    rss_mib = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
+    rss_max = rss_mib
+    if dist.is_initialized():
+        t_rss = torch.tensor([rss_mib], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t_rss, op=dist.ReduceOp.MAX)
+        rss_max = float(t_rss[0])
     if rank == 0:
         images = B * N * args.steps
         value = images / elapsed
@@ -688,6 +695,8 @@ def main():
                     (value / N) * fpi / (MFMA_PEAK_TFLOPS * 1e12) if fpi else None,
             },
             'device': dict(info, **device_state), 'setup_s': t_setup,
+            # peak resident set of a rank's host process (MiB): rank 0's, and the largest over the ranks
+            'host_rss_mib': {'rank0': rss_mib, 'max_over_ranks': rss_max},
         }
         line['roofline']['best_kernel'] = best_kernel_leg(dev)
         line['roofline']['frac_best_kernel'] = line['roofline']['best_kernel']['frac']
