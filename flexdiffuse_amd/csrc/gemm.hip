@@ -1131,6 +1131,12 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         // 256x256 with 64x64 wave tiles: fewer LDS reads per MAC; needs whole rounds of tiles
         const long long t15 = (long long)fd_cdiv(g.M, 256) * fd_cdiv(g.N, 256);
         if (g.N % 256 == 0 && (t15 % 256 == 0 || t15 >= 512 || (t15 >= 128 && t15 <= 256))) best_tile = 15;
+        // K >= 1280 (the 16x16 and 8x8 levels, >= 20 K-tiles per tile): the ping-pong 256x256 tile, 3-8 % faster than the persistent
+        // 16-wave tile; at K = 640 it is 3-5 % slower, at K = 320 (5 K-tiles: un-overlapped prologue + epilogue) 15 % slower
+        if (g_pp && g_use_dma && g_fast_epi && g_bias_lds && g.K >= 1280 && g.M % 256 == 0 && g.N % 256 == 0 && batch == 1 && !d->tile) {
+            g.split_k = 1;
+            if (fd_gemm_pp_ok(g, batch, 31)) best_tile = 31;
+        }
     } else if (g.N <= 64) {
         best_tile = (g.M <= 64) ? 4 : 3;
     } else if (g.K <= 640 || (g.K <= 1280 && tiles_wide < 512)) {
@@ -1214,7 +1220,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     // over K until ~every CU has a workgroup -- or 128x320 tiles (+7..18 %), and the long-K linears of the feed-forward output
     // (+13..14 %).  Convolutions with the ResBlock shortcut appended (their A2 rows stream from HBM inside a few K-tiles),
     // GEGLU and the short-K projections stay on the 2-barrier kernels (equal or faster there); FD_GEMM_PP=0 switches the rule off.
-    if (g_pp && g_use_dma && g_fast_epi && g_bias_lds && !geglu && !d->ln_stats_out && !g.ln_stats && (batch == 1 || g.phase) && !g.out_f32 &&
+    if (g_pp && g_use_dma && g_fast_epi && g_bias_lds && !geglu && !d->ln_stats_out && (!g.ln_stats || g.mode != MODE_CONV) && (batch == 1 || g.phase) && !g.out_f32 &&
         g.act == FD_ACT_NONE && g.N % 320 == 0 && g.M % 128 == 0 && (g.ldc & 7) == 0 && (!g.res || (g.ldr & 3) == 0) &&
         (!g.bias2 || g.rows_per_batch % 256 == 0)) {
         // (the parity-decomposed upsample convolution is four launch slices -- blockIdx.z -- of the same tile grid: no split-K there)
@@ -1237,7 +1243,9 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                 }
             }
             if (!tile && t32 >= 200 && fd_round_eff(t32, 256) >= 0.85) tile = 32, split = 1;
-        } else if (g.mode != MODE_CONV && g.K + g.K2 >= 1280) {
+        } else if (g.mode != MODE_CONV && (g.K + g.K2 >= 1280 || (g.K + g.K2 >= 640 && g.N >= 1280))) {
+            // FF-out (+ folded proj_out, + residual) and the wide LayerNorm-folded projections (fused q|k at the 32x32 / 16x16 levels:
+            // 30.6 vs 35.0 us and 29.1 vs 32.0 us, tools/ab_pp_recorded.py)
             if (t30 >= 200 && fd_round_eff(t30, 256) >= 0.85) tile = 30;
             else if (t32 >= 200 && fd_round_eff(t32, 256) >= 0.85) tile = 32;
         }
@@ -1326,7 +1334,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                      "fd_gemm_f16: ping-pong tile %d cannot run M=%d N=%d K=%d (full tiles, K %% 64 == 0, conv: Wo %% 8 == 0, no fused upsample)",
                      best_tile, g.M, g.N, g.K);
     fd_prof_begin(FD_FAMILY_GEMM, st, flops, flops_exec);
-    if (g.ln_stats && !(best_tile == 9 || best_tile == 10 || (best_tile >= 12 && best_tile <= 16) || best_tile == 20 || best_tile == 23)) {
+    if (g.ln_stats && !(best_tile == 9 || best_tile == 10 || (best_tile >= 12 && best_tile <= 16) || best_tile == 20 || best_tile == 23 || best_tile >= 30)) {
         // small problems: the generic epilogue with the fold compiled in (64x64 for few rows)
         rc = best_tile == 4 ? launch_mode<64, 64, false, false, 2, 2, 2, 7>(g, batch, st)
                             : launch_mode<128, 128, false, false, 2, 2, 2, 7>(g, batch, st);

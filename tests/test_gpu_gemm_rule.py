@@ -14,7 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-CANDIDATE_TILES = (9, 12, 13, 14, 15, 16, 20, 30, 32, 33)
+CANDIDATE_TILES = (9, 12, 13, 14, 15, 16, 20, 30, 31, 32, 33)
 CANDIDATE_SPLITS = (1, 2, 4, 8)
 
 
@@ -51,9 +51,9 @@ def test_rule_is_within_margin_of_the_best_forced_tile():
             continue
         cands = []
         for tile in CANDIDATE_TILES:
-            if (tile in (15,) and k['N'] % 256) or (tile in (16, 30, 32) and k['N'] % 320) or (tile >= 30 and (k['lno'] or k['trans'])):
+            if (tile in (15, 31) and k['N'] % 256) or (tile in (16, 30, 32) and k['N'] % 320) or (tile >= 30 and (k['lno'] or k['trans'])):
                 continue
-            if k['act'] == 4 and tile not in (14, 15):
+            if k['act'] == 4 and tile not in (14, 15, 31):
                 continue
             for sk in CANDIDATE_SPLITS:
                 if sk > 1 and (k['act'] == 4 or k['batch'] > 1 or k['lnf'] or k['lno'] or k['K2'] or (k['K'] // 64) // sk < 8 or
@@ -80,10 +80,22 @@ def test_rule_is_within_margin_of_the_best_forced_tile():
         k = dict(zip(gemm_recorder.KEY_FIELDS, key))
         print(f"M={k['M']:6d} N={k['N']:5d} K={k['K']:5d} {gemm_recorder.describe(key):24s} x{cnt:2d}: rule {a * 1e3:7.1f} us, best forced {c} {b * 1e3:7.1f} us")
     print(f'rule {tot_auto:.2f} ms per forward over the guarded launches, best-per-launch of the candidate set {tot_best:.2f} ms')
-    # in total the rule may trail the per-launch optimum of this candidate set by 3 %; a single launch that matters (>= 1 % of the total)
-    # by 8 % (run-to-run noise of one launch pair is ~3 %)
+    # in total the rule may trail the per-launch optimum of this candidate set by 3 % (noise averages out over ~60 launches); a
+    # single launch that matters (>= 1 % of the total) by 10 % -- one launch pair moves by +-5 % between measurements on this pool, so
+    # a suspect is re-timed (five more interleaved rounds) before it fails the test
     assert tot_auto <= 1.03 * tot_best, (tot_auto, tot_best)
     for ta, tb, a, b, c, key, cnt in rows:
-        if ta >= 0.01 * tot_auto:
-            assert a <= 1.08 * b, (gemm_recorder.describe(key), key[:3], 'rule', a, 'best', c, b)
+        if ta >= 0.01 * tot_auto and a > 1.10 * b:
+            d = rec[key][0]
+
+            def run(tile, sk):
+                d.tile, d.split_k = tile, sk
+                return lib.fd_gemm_f16(ctypes.byref(d), st)
+            a2, b2 = [], []
+            for _ in range(5):
+                a2.append(_time(lambda: run(0, 0), 8))
+                b2.append(_time(lambda: run(*c), 8))
+            d.tile, d.split_k = 0, 0
+            a2, b2 = sorted(a2)[2], sorted(b2)[2]
+            assert a2 <= 1.10 * b2, (gemm_recorder.describe(key), key[:3], 'rule', a2, 'best', c, b2)
     del keep
