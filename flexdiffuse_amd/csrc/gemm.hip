@@ -1364,7 +1364,11 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         //  measured identical to the 2-stage tile on every deep-level convolution, profiles/r04_session_ab.txt sec. 5: not instantiated)
         default: rc = launch<128, 128, false>(g, batch, st); break;
     }
+#ifdef FD_SPLITK_NO_FINISH   // timing-only variant (tools/seam_probe.py): the chain without the finish launch
+    if (false) {
+#else
     if (rc == FD_OK && g.split_k > 1) {
+#endif
         const size_t total = (size_t)g.M * (g.N / 4);
         const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
         hipLaunchKernelGGL(k_splitk_finish, dim3(blocks), dim3(256), 0, st, g);

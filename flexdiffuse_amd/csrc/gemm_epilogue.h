@@ -353,6 +353,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
     // ---- split-K: raw fp32 partial tile, reduced + finished by k_splitk_finish ------------
     if (g.split_k > 1) {
         float* __restrict__ P = g.ws + (size_t)(kslice >= 0 ? kslice : (int)blockIdx.y) * g.M * g.N;
+#ifdef FD_SPLITK_NO_STORE   // timing-only variant (tools/seam_probe.py): the partial pass without its slab stores
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(acc[i][j]));
+        if (g.M < 0) P[0] = 0.f;
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + wm * WTM + i * 16 + fr;

@@ -376,7 +376,13 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) *reinterpret_cast<floatx4*>(P + (size_t)i * 16 * g.N + j * 16) = acc[i][j];
+            for (int j = 0; j < NI; ++j) {
+#ifdef FD_SPLITK_NO_STORE   // timing-only variant (tools/seam_probe.py)
+                asm volatile("" ::"v"(acc[i][j]));
+                if (g.M < 0)
+#endif
+                *reinterpret_cast<floatx4*>(P + (size_t)i * 16 * g.N + j * 16) = acc[i][j];
+            }
     } else if constexpr (EPI == 0 || EPI == 7)
         gemm_epilogue<BM, BN, false, WM_, WN_, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
                                                          b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr, kslice);
