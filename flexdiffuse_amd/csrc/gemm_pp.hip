@@ -56,14 +56,21 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
     const int fr = lane & 15, fq = lane >> 4;
     const int nb = g.tiles_m * g.tiles_n;
     int id = blockIdx.x;
-    {
+    int kslice = blockIdx.y;
+    if (g.sk_flat) {
+        // split-K on a flat grid, K slices pinned to XCDs (workgroup b runs on XCD b % 8): the 8 / split_k XCDs of a slice share that
+        // slice's weights and input channels, so every weight byte is fetched into 8 / split_k L2s instead of all eight
+        // (PMC, 16x16-level conv, 256x320 x split 4 on the 2-D grid: 248 MB read for 50 MB of operands)
+        const int per = 8 / g.split_k, xcd = id & 7, slot = id >> 3;     // split_k in {2, 4, 8}, nb % per == 0
+        kslice = xcd / per;
+        id = (xcd % per) * (nb / per) + slot;                            // each XCD of the slice owns a contiguous range of tiles
+    } else {
         const int q = nb >> 3, r = nb & 7, xcd = id & 7, slot = id >> 3;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     const int tile_n = id % g.tiles_n, tile_m = id / g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z;
-    const int kslice = blockIdx.y;
     // conv: the descriptor starts pad_l pixels BEFORE the tensor, so that the scalar offset of a row group whose leftmost tap
     // column is -pad_l stays >= 0 (the lanes of such columns never load: their voffset is out of range)
     const int pad_t = CONV ? (g.phase ? 1 - (z >> 1) : g.pad_t) : 0, pad_l = CONV ? (g.phase ? 1 - (z & 1) : g.pad_l) : 0;
@@ -426,7 +433,14 @@ static int pp_launch_k2(GemmArgs& g, int batch, hipStream_t st) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    hipLaunchKernelGGL((k_gemm_f16_pp<WM_, WN_, MI, NI, CONV, EPI, HAS_K2>), dim3(g.tiles_m * g.tiles_n, g.split_k, batch), dim3(512), lds, st, g,
+    // split-K slices pinned to XCDs on a flat grid (see the kernel): -3.5..4 % on the 16x16-level convolutions (128-130 / 218-221 / 174-179 us
+    // against 132-136 / 227-232 / 182-186, four interleaved samples each, profiles/r05_ab_pp.txt), neutral at split 2; FD_PP_SK_XCD=0: the 2-D grid (A/B)
+    static const int sk_xcd = getenv("FD_PP_SK_XCD") ? atoi(getenv("FD_PP_SK_XCD")) : 1;
+    const int nb = g.tiles_m * g.tiles_n;
+    g.sk_flat = sk_xcd && (g.split_k == 2 || g.split_k == 4 || g.split_k == 8) && batch == 1 && nb % (8 / g.split_k) == 0 &&
+                (nb * g.split_k) % 8 == 0;
+    const dim3 grid = g.sk_flat ? dim3(nb * g.split_k, 1, batch) : dim3(nb, g.split_k, batch);
+    hipLaunchKernelGGL((k_gemm_f16_pp<WM_, WN_, MI, NI, CONV, EPI, HAS_K2>), grid, dim3(512), lds, st, g,
                        (unsigned)a_bytes, (unsigned)w_bytes);
     FD_CHECK_LAUNCH("k_gemm_f16_pp");
     return FD_OK;
