@@ -80,6 +80,28 @@ def test_pp_split_k_and_appended_phase(dev, tile):
     close(ops.gemm(a.half().to(dev), lw1), a @ w[:, :K].T + b)
 
 
+@pytest.mark.parametrize('tile', [30, 32])
+def test_pp_split_k_slices_pinned_to_xcds(dev, tile):
+    '''Tile counts that are multiples of 8 / split_k take the flat split-K grid (K slices pinned to XCDs: slice = (block % 8) / (8 / split_k)):
+    every (tile, slice) pair must be visited exactly once -- linear GEMM and convolution, split 2 / 4 / 8.'''
+    from flexdiffuse_amd import ops
+    bm, bn = TILES[tile]
+    M, N, K = 8 * bm, 2 * bn, 1536
+    a, w, b = rnd((M, K), 21), rnd((N, K), 22, K ** -0.5), rnd((N,), 23)
+    lw = ops.prep_linear(w, b, dev)
+    ops.FORCE_TILE = tile
+    for split in (2, 4, 8):
+        ops.FORCE_SPLIT = split
+        close(ops.gemm(a.half().to(dev), lw), a @ w.T + b)
+    B, H, W, cin, cout = 8, 16, 16 * bm // 256, 128, bn          # 8 m-tiles
+    x, cw, cb = rnd((B, cin, H, W), 24), rnd((cout, cin, 3, 3), 25, (9 * cin) ** -0.5), rnd((cout,), 26)
+    want = F.conv2d(x, cw, cb, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    for split in (2, 4):
+        ops.FORCE_SPLIT = split
+        y = ops.conv2d(ops.nchw_to_nhwc(x.to(dev)), ops.prep_conv(cw, cb, dev))
+        close(y.t[:, :cout], want)
+
+
 def test_pp_geglu_and_layernorm_fold(dev):
     from flexdiffuse_amd import ops
     M, C = 512, 320
