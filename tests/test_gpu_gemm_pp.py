@@ -162,6 +162,24 @@ def test_pp_conv3x3(dev, tile):
     close(y.t[:, :cout], nhwc(want) + xs @ ws.view(cout, cx).T + bs)
 
 
+@pytest.mark.parametrize('tile', [30, 32])
+def test_pp_conv_stride2_and_asymmetric_padding(dev, tile):
+    '''The rule can hand a stride-2 (Downsample2D) convolution to a ping-pong tile at larger batches: stride 2 with symmetric padding 1, and
+    the UNet's downsampler form (no top / left padding, one row / column of zeros at the bottom / right: pad (0, 0) with out = in / 2).'''
+    from flexdiffuse_amd import ops
+    bm, bn = TILES[tile]
+    B, H, W, cin, cout = 4, 32, 32, 64, bn            # out 16 x 16: M = 1024 = 4 or 8 tiles
+    x, w, b = rnd((B, cin, H, W), 31), rnd((cout, cin, 3, 3), 32, (9 * cin) ** -0.5), rnd((cout,), 33)
+    cw = ops.prep_conv(w, b, dev)
+    xa = ops.nchw_to_nhwc(x.to(dev))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    ops.FORCE_TILE = tile
+    y = ops.conv2d(xa, cw, stride=2)
+    close(y.t[:, :cout], nhwc(F.conv2d(x, w, b, stride=2, padding=1)))
+    y = ops.conv2d(xa, cw, stride=2, pad=(0, 0), out_hw=(H // 2, W // 2))
+    close(y.t[:, :cout], nhwc(F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)))
+
+
 def test_pp_refuses_what_it_cannot_run(dev):
     from flexdiffuse_amd import ops
     ops.FORCE_TILE = 30
