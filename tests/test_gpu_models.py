@@ -1122,6 +1122,17 @@ def test_sd15_stress_weights_forward_and_loop_vs_oracle(sd15, dev):
         print(f'stress preset {name} {kw}: full-size UNet forward (64x64 latents) rel err {e:.4f}, |eps| max {float(want.abs().max()):.2f}')
         assert bool(torch.isfinite(got).all()) and e < 3e-2, (name, e)
         unets[name] = (sd, unet)
+    # ---- preset C: preset A with conv_in x 300 -- the residual stream (and every skip connection) of the 64x64 level sits at
+    # |max| ~1500, std ~290 in fp16 storage (trained checkpoints have such channels); the oracle stays well-conditioned there
+    sdc = build.stress_unet_state_dict('sd15', seed=3, branch_gain=1.0, qk_gain=1.5, gn_shift=6.0)
+    sdc['conv_in.weight'] = sdc['conv_in.weight'] * 300.0
+    sdc = {k: v.half().float() for k, v in sdc.items()}
+    xc = x[:, :, :32, :32].contiguous()
+    got = UNet2DConditionModel(sdc, ucfg, dev)(xc.to(dev), 500, encoder_hidden_states=ctx[1:2].to(dev)).sample
+    want = unet_ref.unet_forward(sdc, ucfg, xc, 500, ctx[1:2])
+    e = relerr(got, want)
+    print(f'stress preset C (A + conv_in x 300: residual stream |max| ~1500): UNet forward (32x32 latents) rel err {e:.4f}')
+    assert bool(torch.isfinite(got).all()) and e < 3e-2, e
     # ---- c1-size loop on preset A (random context pair instead of CLIP outputs: the text tower is not under test)
     sd, unet = unets['A']
     steps, guidance, hw = 10, 8.0, 256
