@@ -421,9 +421,16 @@ int main(int argc, char** argv) {
             fails += moved != 0;
         }
     }
-    // ---- timing: interleaved rounds, 40 launches each, random operands in [-2, 2)
+    // ---- timing: interleaved rounds, 40 launches each, random operands in [-2, 2); argv[3] = "zero": all-zero operands (the same
+    // instruction stream at a lower power draw: what the clock gives back when the multipliers do not toggle)
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const bool zero_fill = argc > 3 && !strcmp(argv[3], "zero");
+    if (zero_fill) {
+        CHECK(hipMemset(A, 0, maxe * 2));
+        CHECK(hipMemset(W, 0, maxe * 2));
+        printf("timing on ALL-ZERO operands\n");
+    }
     for (int size : {big, 8192}) {
         const int M = size, N = size, K = size;
         const double fl = 2.0 * M * N * (double)K;
