@@ -180,6 +180,37 @@ def test_pp_conv_stride2_and_asymmetric_padding(dev, tile):
     close(y.t[:, :cout], nhwc(F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)))
 
 
+def test_pp_agrees_with_the_2barrier_kernels_at_full_size(dev):
+    '''BASELINE configs[1] sizes (CFG batch 16): the ping-pong kernels against the 2-barrier kernels of gemm.hip on the SAME device inputs -- two
+    independent main loops, DMA address paths and K orders computing the same fp32 sums: the level-0 convolution (tile 30 vs 16), the
+    16x16-level convolution with split-K (256x320 x 4 slices pinned to XCDs vs 256x160 x 2), FF-out with the folded proj_out operand and a
+    residual (tile 30 vs 16).  fp16 outputs of the two paths may differ by one rounding of a sum accumulated in another order.'''
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(3)
+
+    def both(fn, arms):
+        outs = []
+        for tile, split in arms:
+            ops.FORCE_TILE, ops.FORCE_SPLIT = tile, split
+            outs.append(fn().float())
+        ops.FORCE_TILE, ops.FORCE_SPLIT = 0, 0
+        ref = outs[-1]
+        for o in outs[:-1]:
+            err = (o - ref).abs()
+            assert bool((err <= 2e-3 * ref.abs() + 2e-3).all()), float(err.max())
+        assert float(ref.abs().max()) > 1.0
+    for (B, H, C, arms) in ((16, 64, 320, ((30, 1), (16, 1))), (16, 16, 1280, ((30, 4), (13, 2)))):
+        x = ops.Act((torch.randn((B * H * H, C), generator=g) * 0.7).half().to(dev), B, H, H)
+        w = ops.prep_conv(torch.randn((C, C, 3, 3), generator=g) * (9 * C) ** -0.5, torch.randn(C, generator=g), dev)
+        b2 = torch.randn((B, C), generator=g).to(dev)
+        both(lambda: ops.conv2d(x, w, bias2=b2, ld_bias2=C).t, arms)
+    M, N, K, K2 = 65536, 320, 1280, 320
+    a, a2 = torch.randn((M, K), generator=g).half().to(dev), torch.randn((M, K2), generator=g).half().to(dev)
+    res = torch.randn((M, N), generator=g).half().to(dev)
+    lw = ops.prep_linear(torch.randn((N, K + K2), generator=g) * K ** -0.5, torch.randn(N, generator=g), dev)
+    both(lambda: ops.gemm(a, lw, a2=a2, residual=res), ((30, 1), (16, 1)))
+
+
 def test_pp_refuses_what_it_cannot_run(dev):
     from flexdiffuse_amd import ops
     ops.FORCE_TILE = 30
