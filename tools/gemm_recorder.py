@@ -10,7 +10,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def record(preset='sd15', lat=64, batch=8, vae=True, dev=None):
+def record(preset='sd15', lat=64, batch=8, vae=True, dev=None, unet=True):
     '''-> (OrderedDict key -> [fd_gemm_desc copy, launches per forward], list of tensors that must stay alive)'''
     import torch
     from flexdiffuse_amd import build, hip, ops
@@ -44,13 +44,15 @@ def record(preset='sd15', lat=64, batch=8, vae=True, dev=None):
     ops._empty = keep_empty
     torch.empty = lambda *a, **k: (keep.append(te(*a, **k)) or keep[-1])
     try:
-        sds = build.synthetic_state_dicts(preset, seed=0, parts=('unet', 'vae') if vae else ('unet',))
+        sds = build.synthetic_state_dicts(preset, seed=0, parts=(('unet',) if unet else ()) + (('vae',) if vae else ()))
         ucfg, vcfg, _ = build.configs(preset)
-        unet = UNet2DConditionModel(sds['unet'], ucfg, dev)
         x = torch.randn((batch, 4, lat, lat), device=dev)
-        ctx = torch.randn((2 * batch, 77, ucfg.cross_attention_dim), device=dev).half()
-        keep += [x, ctx, unet]
-        unet.forward_nhwc(x, 500, ctx, rep=2)
+        keep.append(x)
+        if unet:
+            net = UNet2DConditionModel(sds['unet'], ucfg, dev)
+            ctx = torch.randn((2 * batch, 77, ucfg.cross_attention_dim), device=dev).half()
+            keep += [ctx, net]
+            net.forward_nhwc(x, 500, ctx, rep=2)
         if vae:
             v = AutoencoderKL(sds['vae'], vcfg, device=dev, encoder=False)
             keep.append(v)
