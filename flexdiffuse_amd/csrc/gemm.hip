@@ -1145,8 +1145,6 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         // on 256x160 otherwise; 8 waves on 128x128 where 160 does not divide N or for GEGLU);
         // tiny row counts keep the 64x64 tile
         best_tile = (g.M <= 1024) ? 4 : (!n160 ? 10 : (g.M <= 4096 ? 12 : 13));
-        // the VAE mid-block attention's batched QK^T (8 x 4096 x 4096 x 512): 256x256 tiles, 171 vs 213 us
-        if (!n160 && g.N % 256 == 0 && g.N >= 1024 && g.M % 256 == 0 && (long long)(g.M / 256) * (g.N / 256) * batch >= 1024) best_tile = 15;
     } else if (n160) {
         // large K, UNet widths: 256x160 with 16 waves (32x80 wave tiles, one workgroup per CU,
         // up to 1.23 PFLOP/s); split K until ~every CU has a workgroup
@@ -1261,12 +1259,13 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         }
     }
     // ... and the VAE decoder's widths (N = 256 / 512, no 160-wide tiles): the ping-pong 256x256 tile is 3-8 % faster than the 2-barrier 256x256
-    // tile on its convolutions from the 64x64 maps up (profiles/r05_gemm_sweep_vae.txt), 10-18 % on its K = 512 attention projections
+    // tile on its convolutions from the 64x64 maps up (profiles/r05_gemm_sweep_vae.txt), 10-18 % on its K = 512 attention projections, 160 vs 213 us on the
+    // mid-block attention's batched QK^T (8 x 4096 x 4096 x 512)
     if (g_pp && g_use_dma && g_fast_epi && g_bias_lds && !geglu && !n160 && !d->ln_stats_out && !g.ln_stats && !g.out_f32 && !d->trans_out && g.act == FD_ACT_NONE &&
-        best_split == 1 && g.N % 256 == 0 && g.N <= 512 && g.M % 256 == 0 && (g.ldc & 7) == 0 && (!g.res || (g.ldr & 3) == 0) &&
+        best_split == 1 && g.N % 256 == 0 && g.M % 256 == 0 && (g.ldc & 7) == 0 && (!g.res || (g.ldr & 3) == 0) &&
         (!g.bias2 || g.rows_per_batch % 256 == 0)) {
         const long long t31 = (long long)(g.M / 256) * (g.N / 256) * batch;
-        const bool pick = g.mode == MODE_CONV ? (nk_all >= 32 && t31 >= (g.phase ? 512 : 256)) : (g.K >= 512 && t31 >= 256);
+        const bool pick = g.mode == MODE_CONV ? (nk_all >= (g.phase ? 16 : 32) && t31 >= (g.phase ? 512 : 256)) : (g.K >= 512 && t31 >= 256);
         if (pick && fd_gemm_pp_ok(g, batch, 31)) best_tile = 31;
     }
     if (d->tile) best_tile = d->tile;
