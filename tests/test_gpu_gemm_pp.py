@@ -42,7 +42,7 @@ def close(got, want, rtol=3e-3, atol=3e-3):
 
 
 @pytest.mark.parametrize('tile', sorted(TILES))
-@pytest.mark.parametrize('K', [64, 192, 320, 1280])
+@pytest.mark.parametrize('K', [64, 128, 192, 256, 320, 1280])
 def test_pp_linear_epilogues(dev, tile, K):
     from flexdiffuse_amd import ops
     bm, bn = TILES[tile]
