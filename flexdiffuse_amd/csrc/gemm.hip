@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
             const int hw = g.Ho * g.Wo;
             const int b = mm / hw, rem = mm - b * hw;
             const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
-            a_off[i] = b * g.Hi * g.Wi * g.Cin + ck * 8;
+            a_off[i] = b * g.Hi * g.Wi * g.Cpix + ck * 8;
             a_y[i] = oy * g.stride - g.pad_t;
             a_x[i] = ox * g.stride - g.pad_l;
         } else {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs g) {
                     iy >>= 1;                                                               \
                     ix >>= 1;                                                               \
                 }                                                                           \
-                const u32x4 v = *(gptr_u4)(Ab + a_off[i] + (iy * g.Wi + ix) * g.Cin + ci0); \
+                const u32x4 v = *(gptr_u4)(Ab + a_off[i] + (iy * g.Wi + ix) * g.Cpix + ci0); \
                 ra[i] = ok ? v : zero4;                                                     \
             }                                                                               \
             ci0 += BK;                                                                      \
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
             const int hw = g.Ho * g.Wo;
             const int b = mm / hw, rem = mm - b * hw;
             const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
-            a_off[i] = b * g.Hi * g.Wi * g.Cin + ck * 8;
+            a_off[i] = b * g.Hi * g.Wi * g.Cpix + ck * 8;
             // phase mode: the 2x2 window of output parity (py, px) = (z >> 1, z & 1) starts one row / column earlier for parity 0
             const int pad_t = g.phase ? 1 - (z >> 1) : g.pad_t, pad_l = g.phase ? 1 - (z & 1) : g.pad_l;
             a_yx[i] = ok ? ((unsigned)(oy * g.stride - pad_t + 16) << 16) |
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
                         iy >>= 1;                                                           \
                         ix >>= 1;                                                           \
                     }                                                                       \
-                    a_voff[i] = ok ? (unsigned)(a_off[i] + (iy * g.Wi + ix) * g.Cin) * 2u   \
+                    a_voff[i] = ok ? (unsigned)(a_off[i] + (iy * g.Wi + ix) * g.Cpix) * 2u   \
                                    : a_bytes;                                               \
                 }                                                                           \
                 new_tap = false;                                                            \
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
                 const int hw = g.Ho * g.Wo;                                                 \
                 const int b = mm / hw, rem = mm - b * hw;                                   \
                 const int oy = rem / g.Wo, ox = rem - oy * g.Wo;                            \
-                a_off[i] = b * g.Hi * g.Wi * g.Cin + ck * 8;                                \
+                a_off[i] = b * g.Hi * g.Wi * g.Cpix + ck * 8;                                \
                 a_y[i] = oy * g.stride - g.pad_t;                                           \
                 a_x[i] = ox * g.stride - g.pad_l;                                           \
                 a_voff[i] = a_bytes;                                                        \
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_f16_dmap(GemmArgs g, u
                         iy >>= 1;                                                           \
                         ix >>= 1;                                                           \
                     }                                                                       \
-                    a_voff[i] = ok ? (unsigned)(a_off[i] + (iy * g.Wi + ix) * g.Cin) * 2u   \
+                    a_voff[i] = ok ? (unsigned)(a_off[i] + (iy * g.Wi + ix) * g.Cpix) * 2u   \
                                    : a_bytes;                                               \
                 }                                                                           \
                 new_tap = false;                                                            \
@@ -832,7 +832,7 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     dim3 grid(g.tiles_m * g.tiles_n, g.split_k, batch);
     // tensor extents for the buffer descriptors of the LDS-DMA loop (must fit 32 bits)
     const unsigned long long a_bytes =
-        CONV ? 2ull * (g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi * g.Cin
+        CONV ? 2ull * (((unsigned long long)(g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi - 1) * g.Cpix + g.Cin)
              : 2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K);
     const unsigned long long w_bytes = 2ull * ((unsigned long long)(g.N - 1) * g.ldw + g.K + g.K2);
     if (g_use_dma && a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull) {
@@ -1034,6 +1034,10 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         g.phase = d->upsample2x == 2;
         FD_CHECK_ARG(d->in_c % BK == 0, FD_ESHAPE,
                      "fd_gemm_f16: conv needs Cin %% 64 == 0 (got %d); use fd_im2col_f16", d->in_c);
+        // the input may be a column slice of a wider NHWC matrix (a skip tensor living in its concat buffer): lda = pixel stride
+        g.Cpix = d->lda > 0 ? d->lda : d->in_c;
+        FD_CHECK_ARG(g.Cpix >= d->in_c && g.Cpix % 8 == 0 && (uintptr_t)d->A % 16 == 0, FD_ESHAPE,
+                     "fd_gemm_f16: conv input pixel stride lda=%d must be 0 (= Cin) or >= Cin=%d and a multiple of 8, A 16-byte aligned", d->lda, d->in_c);
         FD_CHECK_ARG(d->K == d->kh * d->kw * d->in_c, FD_EINVAL, "fd_gemm_f16: K != kh*kw*Cin");
         FD_CHECK_ARG(d->M % (d->out_h * d->out_w) == 0, FD_EINVAL,
                      "fd_gemm_f16: M is not a multiple of out_h*out_w");
@@ -1293,7 +1297,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         // tensor through 32-bit byte offsets (< 2 GiB).  Larger operands go to the register-staged
         // 4-wave kernel (32-bit ELEMENT offsets: < 2^31 halfs = 4 GiB); beyond that, refuse.
         const unsigned long long a_elems =
-            g.mode == MODE_CONV ? (unsigned long long)(g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi * g.Cin
+            g.mode == MODE_CONV ? ((unsigned long long)(g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi - 1) * g.Cpix + g.Cin
                                 : (unsigned long long)(g.M - 1) * g.lda + g.K;
         const unsigned long long w_elems = (unsigned long long)(g.N - 1) * g.ldw + g.K;
         const unsigned long long c_elems = (unsigned long long)(g.M - 1) * g.ldc + g.N;

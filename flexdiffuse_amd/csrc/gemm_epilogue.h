@@ -26,6 +26,7 @@ struct GemmArgs {
     int M, N, K, lda, ldw, ldc, ldr, ldb2;
     int mode;
     int Hi, Wi, Cin, Ho, Wo, KW, stride, pad_t, pad_l, up;
+    int Cpix;   // conv: pixel stride of the NHWC input in halfs (>= Cin: the input may be a column slice of a wider matrix)
     int rows_per_batch;
     int act, out_f32, trans_out;
     long long strideT;  // per-sample stride of the transposed output

@@ -17,6 +17,10 @@
 //     one wave is inside its MFMA section while its partner issues the reads and DMAs of its next one.
 //   Ordering (MI355X_MICROARCH.md, two waves per SIMD, item 7): a piece is read one phase after the phase whose counted
 //   vmcnt retired it in every wave (RAW), and overwritten no sooner than two phases after its last ds_read (WAR).
+//   EVERY phase waits: phase P stages piece P + 6 and its vmcnt(one K-tile's worth) retires pieces <= P + 2, i.e. phase 3 --
+//   which reads nothing itself -- retires the B0 piece that phase 0 of the next K-tile reads first.  (Until late in round 5
+//   phase 3 did not wait: B0 was then read on the strength of having been issued five phases earlier, and about one launch in
+//   25,000 read a row group that had not landed -- found as a sporadic graph-vs-plan mismatch of the 50-step loop.)
 //
 // DMA addressing is scalar: an 8-row DMA group is 8 consecutive rows of A (or 8 consecutive pixels of one image row for a
 // convolution: Wo % 8 == 0), so the per-lane part of the source offset is a constant and everything else (row base, filter
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
     // conv: the descriptor starts pad_l pixels BEFORE the tensor, so that the scalar offset of a row group whose leftmost tap
     // column is -pad_l stays >= 0 (the lanes of such columns never load: their voffset is out of range)
     const int pad_t = CONV ? (g.phase ? 1 - (z >> 1) : g.pad_t) : 0, pad_l = CONV ? (g.phase ? 1 - (z & 1) : g.pad_l) : 0;
-    const int a_shift = pad_l * g.Cin;   // halfs
+    const int a_shift = pad_l * g.Cpix;   // halfs
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(g.A + (size_t)z * g.strideA - a_shift), 0, a_bytes + 2u * (unsigned)a_shift, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
@@ -197,8 +201,8 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
         const int ok_ = t_cur < nk ? 1 : 0;                                                                 \
         int pixb_, asoff_, kh_;                                                                             \
         if (CONV) {                                                                                         \
-            pixb_ = a2_ ? g.lda2 * 2 : g.Cin * 2;                                                           \
-            asoff_ = a2_ ? (pad_t * g.Wi * g.lda2 + a_idx * BK) * 2 : ((c_kh * g.Wi + c_kw) * g.Cin + c_ci0) * 2; \
+            pixb_ = a2_ ? g.lda2 * 2 : g.Cpix * 2;                                                          \
+            asoff_ = a2_ ? (pad_t * g.Wi * g.lda2 + a_idx * BK) * 2 : ((c_kh * g.Wi + c_kw) * g.Cpix + c_ci0) * 2; \
             kh_ = a2_ ? pad_t : c_kh;                                                                       \
         } else {                                                                                            \
             pixb_ = a2_ ? g.lda2 * 2 : g.lda * 2;                                                           \
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
 #define PP_ISSUE_A(MIH, PAR)                                                                                \
     {                                                                                                       \
         const bool a2_ = PP_IS_A2();                                                                        \
-        const int pixs_ = a2_ ? g.lda2 * 2 : (CONV ? g.stride * g.Cin * 2 : g.lda * 2);                     \
+        const int pixs_ = a2_ ? g.lda2 * 2 : (CONV ? g.stride * g.Cpix * 2 : g.lda * 2);                    \
         const int kw_ = a2_ ? pad_l : c_kw;                                                                 \
         const unsigned lanev_ = (unsigned)(rsub * pixs_) + ck16;                                            \
         _Pragma("unroll") for (int i = 0; i < CA; ++i) {                                                    \
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
         if (ph_ == 1) { PP_READ_B1(par_); }                                                                 \
         if (ph_ == 2) { PP_READ_A(1, par_); }                                                               \
         PP_ISSUE(((P) + 6) & 3, (((P) + 6) >> 2) & 1);                                                      \
-        if (ph_ != 3) { PP_WAIT(); }                                                                        \
+        PP_WAIT();                                                                                          \
         PP_STAMP(ts_b[ph_])                                                                                 \
         PP_BAR();                                                                                           \
         if (ph_ == 0) { PP_MFMA(0, fb0, NI0, 0); }                                                          \
@@ -424,7 +428,7 @@ static int pp_launch_k2(GemmArgs& g, int batch, hipStream_t st) {
     g.tiles_m = g.M / BM;
     g.tiles_n = g.N / BN;
     const size_t lds = 2 * (size_t)(BM + BN) * 128 + 4 * BN * sizeof(float);
-    const unsigned long long a_bytes = CONV ? 2ull * (g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi * g.Cin
+    const unsigned long long a_bytes = CONV ? 2ull * (((unsigned long long)(g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi - 1) * g.Cpix + g.Cin)
                                             : 2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K);
     const unsigned long long w_bytes = 2ull * ((unsigned long long)(g.N - 1) * g.ldw + g.K + g.K2);
     static bool configured = false;
@@ -517,7 +521,7 @@ bool fd_gemm_pp_ok(const GemmArgs& g, int batch, int tile) {
     if (!bm) return false;
     if (g.M % bm != 0 || g.N % bn != 0 || g.K % BK != 0 || g.K2 % BK != 0 || g.trans_out) return false;
     if (g.act == FD_ACT_GEGLU && (bn / (tile == 33 ? 2 : 4)) % 32 != 0) return false;   // value / gate fragment pairs per wave
-    const unsigned long long a_bytes = g.mode == MODE_CONV ? 2ull * (g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi * g.Cin
+    const unsigned long long a_bytes = g.mode == MODE_CONV ? 2ull * (((unsigned long long)(g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi - 1) * g.Cpix + g.Cin)
                                                            : 2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K);
     const unsigned long long w_bytes = 2ull * ((unsigned long long)(g.N - 1) * g.ldw + g.K + g.K2);
     if (a_bytes >= 0x7ffffff0ull || w_bytes >= 0x7ffffff0ull) return false;

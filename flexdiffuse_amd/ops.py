@@ -383,7 +383,9 @@ def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), 
     if out is None:
         out = _empty((M, _round_up(w.cout, 4)), torch.float32 if out_f32 else torch.float16, x.t)
     assert out.shape == (M, _round_up(w.cout, 4)) and out.stride(1) == 1
-    assert x.t.is_contiguous(), 'conv input must be a contiguous NHWC matrix'
+    # the implicit-GEMM loaders take a pixel stride: x may be a column slice of a wider matrix (a skip tensor in its concat buffer)
+    assert x.t.stride(1) == 1 and (x.t.is_contiguous() or (not w.im2col and x.t.stride(0) % 8 == 0 and x.t.data_ptr() % 16 == 0)), \
+        'conv input must be an NHWC matrix with unit channel stride (contiguous for the explicit-im2col path)'
     d = fd_gemm_desc()
     d.W, d.C = w.w.data_ptr(), out.data_ptr()
     d.bias, d.bias2, d.residual = _p(w.bias), _p(bias2), _p(residual)
@@ -401,7 +403,7 @@ def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), 
                  w.kh, w.kw, stride, pad[0], pad[1], w.kpad, hip.stream())
         d.A, d.lda = cols.data_ptr(), w.kpad
     else:
-        d.A = x.t.data_ptr()
+        d.A, d.lda = x.t.data_ptr(), x.t.stride(0)
         d.conv, d.in_h, d.in_w, d.in_c = 1, x.H, x.W, w.cin
         d.out_h, d.out_w, d.kh, d.kw = Ho, Wo, w.kh, w.kw
         d.stride, d.pad_t, d.pad_l, d.upsample2x = stride, pad[0], pad[1], int(up)

@@ -195,14 +195,16 @@ class UNet2DConditionModel():
         (diffusers' torch.cat in the up blocks).  Instead of copying both halves, every skip is
         written by its producer straight into the right-hand columns of a [M][Ch + Cs] buffer and
         the decoder op that produces h writes the left-hand columns.  Returns, per skip in
-        encoder order, the Ch of the decoder tensor it will meet -- or None for the skips that
-        feed a downsample conv (the conv loader wants a contiguous NHWC input).'''
+        encoder order, the Ch of the decoder tensor it will meet (None: an ordinary tensor and a
+        copying concat).  Every consumer of a skip takes a row stride -- GroupNorm, the residual /
+        shortcut operands, and the implicit-GEMM loader of the downsample convolutions (pixel stride).'''
         skip_c, excluded = [self.conv_in.cout], set()
         for blk in self.down:
             for r in blk['res']:
                 skip_c.append(r.cout)
             if blk['down'] is not None:
-                excluded.add(len(skip_c) - 1)          # input of the downsample conv
+                if blk['down'].im2col:
+                    excluded.add(len(skip_c) - 1)      # narrow inputs (Cin % 64 != 0): the explicit im2col wants contiguous rows
                 skip_c.append(blk['down'].cout)
         plan: List[Optional[int]] = [None] * len(skip_c)
         c, i = self.mid_res1.cout, len(skip_c) - 1

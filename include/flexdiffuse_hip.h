@@ -147,7 +147,7 @@ int fd_guidance_header_pull(float* out, const float* hdr, int B, int L, int D, v
 #define FD_ACT_GEGLU 4      /* value * gelu(gate); weight rows interleaved 16 value / 16 gate */
 
 typedef struct fd_gemm_desc {
-    const void* A;        /* fp16: linear [M][lda]; conv: NHWC input [B][in_h][in_w][in_c] */
+    const void* A;        /* fp16: linear [M][lda]; conv: NHWC input [B][in_h][in_w][in_c], pixel stride lda halfs (0 = in_c; >= in_c, % 8) */
     const void* W;        /* fp16 [N][ldw], K contiguous (conv: [Cout][kh][kw][Cin]) */
     void* C;              /* fp16 (or fp32 if out_f32) [M][ldc]; GEGLU: [M][N/2] */
     const float* bias;    /* [N] or NULL */

@@ -220,3 +220,40 @@ def test_pp_refuses_what_it_cannot_run(dev):
     x, cw = rnd((1, 64, 16, 20), 3), rnd((320, 64, 3, 3), 4, 0.05)
     with pytest.raises(ValueError):          # Wo % 8 != 0
         ops.conv2d(ops.nchw_to_nhwc(x.to(dev)), ops.prep_conv(cw, None, dev))
+
+
+@pytest.mark.parametrize('tile', sorted(TILES))
+@pytest.mark.parametrize('M,N,K', [(256, 81920, 320), (512, 40960, 2560)])
+def test_pp_race_screen_with_weights_streaming_from_hbm(dev, tile, M, N, K):
+    '''Race screen of the LDS ring.  The counted vmcnt of EVERY phase is what orders a piece's LDS-DMA before its ds_read; a missing wait
+    does not show up in the refchecks above, whose weights sit in L2: the piece was issued several phases earlier and has landed.
+    (Round 5: phase 3 did not wait, so the B0 piece of the next K-tile was read unretired -- about one launch in 25,000 of a forward
+    went wrong, found as a sporadic graph-vs-plan mismatch of the 50-step loop.)  Here W is 50-200 MB and every tile reads its own rows of
+    it exactly once, so every B piece is an HBM miss, and the short MFMA sections of the 64-row wave tiles leave the least time between
+    issue and read: a build without phase 3's wait fails this test in every launch on tiles 32 / 33 (checked against such a build);
+    the result must agree with torch and repeat bit for bit.'''
+    from flexdiffuse_amd import ops
+    bm, bn = TILES[tile]
+    if M % bm or N % bn:
+        pytest.skip('partial tiles')
+    g = torch.Generator().manual_seed(17)
+    a = torch.randn((M, K), generator=g).half().to(dev)
+    w = (torch.randn((N, K), generator=g) * K ** -0.5).half()
+    lw = ops.prep_linear(w.float(), torch.zeros(N), dev)
+    want = a.float() @ w.to(dev).float().t()
+    old = ops.FORCE_TILE
+    ops.FORCE_TILE = tile
+    try:
+        ref = ops.gemm(a, lw).clone()
+        torch.cuda.synchronize()
+        err = float((ref.float() - want).abs().max())
+        assert err < 2e-2 * max(1.0, float(want.abs().max())), err
+        out = torch.empty_like(ref)
+        bad = torch.zeros((), dtype=torch.int64, device=dev)
+        for _ in range(60):
+            ops.gemm(a, lw, out=out)
+            bad += (out != ref).sum()
+        torch.cuda.synchronize()
+        assert int(bad) == 0, int(bad)
+    finally:
+        ops.FORCE_TILE = old

@@ -149,6 +149,68 @@ def test_conv3x3_implicit(dev, cin, cout, H, W, stride, up):
     close(got, want, rtol=3e-3, atol=3e-3)
 
 
+@pytest.mark.parametrize('tile', [0, 2, 9, 13, 16, 20, 30, 32, 33])
+@pytest.mark.parametrize('stride,up', [(1, False), (2, False), (1, True)])
+def test_conv_input_with_a_pixel_stride(dev, tile, stride, up):
+    '''The input of a convolution may be a column slice of a wider NHWC matrix (fd_gemm_desc.lda = pixel stride: a skip tensor
+    living in the right-hand columns of its concat buffer feeds the UNet's downsample convolution).  Same kernels, same
+    arithmetic, other addresses: bit-identical to the contiguous input, for every loader (register-staged, LDS-DMA one-tile /
+    persistent, ping-pong), stride 1 / 2 and the fused nearest upsample; the neighbouring columns hold NaN.'''
+    from flexdiffuse_amd import ops
+    if up and tile >= 30:
+        pytest.skip('the ping-pong tiles have no fused nearest upsample')
+    B, H, W, cin, cout, left = 2, 32, 32, 320, 320, 192
+    x, w, b = rnd((B * H * W, cin), 1), rnd((cout, cin, 3, 3), 2, (9 * cin) ** -0.5), rnd((cout,), 3)
+    cw = ops.prep_conv(w, b, dev)
+    wide = torch.full((B * H * W, left + cin + 64), float('nan'), dtype=torch.float16, device=dev)
+    wide[:, left:left + cin] = x.half().to(dev)
+    xc = ops.Act(x.half().to(dev), B, H, W)
+    xs = ops.Act(wide[:, left:left + cin], B, H, W)
+    assert not xs.t.is_contiguous()
+    old = ops.FORCE_TILE
+    ops.FORCE_TILE = tile
+    try:
+        want = ops.conv2d(xc, cw, stride=stride, up=up).t.clone()
+        got = ops.conv2d(xs, cw, stride=stride, up=up).t
+    finally:
+        ops.FORCE_TILE = old
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got, want)
+
+
+def test_conv_pixel_stride_on_the_register_staged_loader(dev):
+    '''...and the 4-wave register-staged kernel (tensors >= 2 GiB; FD_GEMM_NO_DMA=1 selects it for everything) in a child process:
+    strided input == contiguous input bit for bit, and both agree with torch.'''
+    import os
+    import subprocess
+    import sys
+    code = '''
+import torch, torch.nn.functional as F
+from flexdiffuse_amd import ops
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(5)
+B, H, W, cin, cout, left = 2, 16, 16, 128, 64, 64
+x = torch.randn((B * H * W, cin), generator=g)
+w = torch.randn((cout, cin, 3, 3), generator=g) * (9 * cin) ** -0.5
+b = torch.randn((cout,), generator=g)
+cw = ops.prep_conv(w, b, dev)
+wide = torch.full((B * H * W, left + cin + 8), float('nan'), dtype=torch.float16, device=dev)
+wide[:, left:left + cin] = x.half().to(dev)
+for stride in (1, 2):
+    want = ops.conv2d(ops.Act(x.half().to(dev), B, H, W), cw, stride=stride)
+    got = ops.conv2d(ops.Act(wide[:, left:left + cin], B, H, W), cw, stride=stride)
+    assert torch.equal(got.t, want.t)
+    ref = F.conv2d(x.half().float().view(B, H, W, cin).permute(0, 3, 1, 2), w.half().float(), b, stride=stride, padding=1)
+    err = (got.t.float().view(B, got.H, got.W, cout).permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
+    assert err < 2e-2, err
+print('ok')
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FD_GEMM_NO_DMA='1', PYTHONPATH=root)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_conv_small_cin_and_asym_pad(dev):
     from flexdiffuse_amd import ops
     B, H, W = 2, 16, 16

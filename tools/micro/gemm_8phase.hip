@@ -151,7 +151,7 @@ __global__ __launch_bounds__(512) void k_gemm_8phase(const half_t* __restrict__ 
         if (ph_ == 1) { READ_B(fb1, 4 * b_ + 2); }                                                                     \
         if (ph_ == 2) { READ_A(4 * b_ + 3); }                                                                          \
         STAGE(kt + (((P) + 6) >> 2), ((P) + 6) & 3, ((P) + 6) & 7, CHK);                                               \
-        if (ph_ != 3) { WAIT_STAGED(); }                                                                               \
+        WAIT_STAGED(); /* every phase: phase 3 retires the W0 piece that phase 0 of the next K-tile reads first */        \
         if (TIMING && !(CHK)) ts_b[ph_] = __builtin_amdgcn_s_memtime();                                                          \
         BAR();                                                                                                         \
         if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                       \
