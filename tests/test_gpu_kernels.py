@@ -211,6 +211,36 @@ print('ok')
     assert r.returncode == 0 and 'ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize('tile', [9, 12, 13, 14, 15, 16, 20, 23])
+def test_lds_dma_tiles_race_screen_with_weights_streaming_from_hbm(dev, tile):
+    '''The race screen of tests/test_gpu_gemm_pp.py for the other LDS-DMA kernels (one-tile 2-stage, 3-stage with counted vmcnt, persistent):
+    a 52 MB weight matrix of which every tile reads its own rows once (every W DMA is an HBM miss), short K loop; the result must agree
+    with torch and repeat bit for bit.'''
+    from flexdiffuse_amd import ops
+    M, N, K = 576, 81920, 320
+    g = torch.Generator().manual_seed(19)
+    a = torch.randn((M, K), generator=g).half().to(dev)
+    w = (torch.randn((N, K), generator=g) * K ** -0.5).half()
+    lw = ops.prep_linear(w.float(), torch.zeros(N), dev)
+    want = a.float() @ w.to(dev).float().t()
+    old = ops.FORCE_TILE
+    ops.FORCE_TILE = tile
+    try:
+        ref = ops.gemm(a, lw).clone()
+        torch.cuda.synchronize()
+        err = float((ref.float() - want).abs().max())
+        assert err < 2e-2 * max(1.0, float(want.abs().max())), err
+        out = torch.empty_like(ref)
+        bad = torch.zeros((), dtype=torch.int64, device=dev)
+        for _ in range(40):
+            ops.gemm(a, lw, out=out)
+            bad += (out != ref).sum()
+        torch.cuda.synchronize()
+        assert int(bad) == 0, int(bad)
+    finally:
+        ops.FORCE_TILE = old
+
+
 def test_conv_small_cin_and_asym_pad(dev):
     from flexdiffuse_amd import ops
     B, H, W = 2, 16, 16
