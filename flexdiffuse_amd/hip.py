@@ -80,7 +80,7 @@ _SIGNATURES = {
     'fd_cast_f16_to_f32': (c_int, [P, P, c_int64, P]),
 }
 
-ABI_VERSION = 9   # FD_ABI_VERSION in include/flexdiffuse_hip.h
+ABI_VERSION = 10  # FD_ABI_VERSION in include/flexdiffuse_hip.h
 _lib: Optional[ctypes.CDLL] = None
 
 

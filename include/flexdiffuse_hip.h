@@ -32,7 +32,7 @@ extern "C" {
 #define FD_ESHAPE (-2) /* unsupported shape / alignment */
 #define FD_EHIP (-3)   /* HIP runtime error */
 
-#define FD_ABI_VERSION 9
+#define FD_ABI_VERSION 10
 
 int fd_abi_version(void);
 const char* fd_last_error(void);
