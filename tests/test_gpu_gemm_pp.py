@@ -234,8 +234,7 @@ def test_pp_race_screen_with_weights_streaming_from_hbm(dev, tile, M, N, K):
     the result must agree with torch and repeat bit for bit.'''
     from flexdiffuse_amd import ops
     bm, bn = TILES[tile]
-    if M % bm or N % bn:
-        pytest.skip('partial tiles')
+    assert M % bm == 0 and N % bn == 0
     g = torch.Generator().manual_seed(17)
     a = torch.randn((M, K), generator=g).half().to(dev)
     w = (torch.randn((N, K), generator=g) * K ** -0.5).half()
