@@ -1143,6 +1143,12 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         }
     } else if (g.N <= 64) {
         best_tile = (g.M <= 64) ? 4 : 3;
+        // the UNet's / VAE's output convolutions (N = 4 / 3, K = 9 C): 16 waves on 128x64; with <= 2 workgroups per CU two K slices
+        // halve the serial K loop (conv_out of the bench forward: 41 vs 54 us, profiles/r05_gemm_sweep_vae.txt)
+        if (g.mode == MODE_CONV && g.M >= 32768 && nk_all >= 32 && batch == 1) {
+            best_tile = 11;
+            if (fd_cdiv(g.M, 128) <= 512 && g.N % 4 == 0 && g.ws && (size_t)2 * g.M * g.N * 4 <= (size_t)d->workspace_bytes) best_split = 2;
+        }
     } else if (g.K <= 640 || (g.K <= 1280 && tiles_wide < 512)) {
         // short K loops (transformer projections, GEGLU, 1x1 shortcuts) are latency-bound:
         // many-wave tiles win by 12-23 % over 4-wave 128x64 (16 waves on 128x160 for few rows,
@@ -1247,6 +1253,15 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                 }
             }
             if (!tile && t32 >= 200 && fd_round_eff(t32, 256) >= 0.85) tile = 32, split = 1;
+            // few rows, long K (the 8x8 level: 1024 x 1280 x 11520 / 23040): 128x320 tiles x up to 8 K slices -- 44.4 vs 46.0 / 66.8 vs 71.4 us
+            // against 256x160 x 8 on the 2-barrier kernel (4 launches each, profiles/r05_gemm_sweep_vae.txt header run)
+            if (!tile && t32 > 0) {
+                int s8 = 1;
+                while (t32 * s8 < 200 && s8 < 8 && nk_all / (s8 * 2) >= 8 && g.ws && g.N % 4 == 0 &&
+                       (size_t)(s8 * 2) * g.M * g.N * 4 <= (size_t)d->workspace_bytes)
+                    s8 *= 2;
+                if (s8 > 1 && t32 * s8 >= 200 && fd_round_eff(t32 * s8, 256) >= 0.85) tile = 32, split = s8;
+            }
         } else if (g.mode != MODE_CONV && (g.K + g.K2 >= 1280 || (g.K + g.K2 >= 640 && g.N >= 1280))) {
             // FF-out (+ folded proj_out, + residual) and the wide LayerNorm-folded projections (fused q|k at the 32x32 / 16x16 levels:
             // 30.6 vs 35.0 us and 29.1 vs 32.0 us, tools/ab_pp_recorded.py)

@@ -22,7 +22,7 @@ NOTES = [   # (substring of the kernel name, key, description, algorithmic bytes
     ('k_gemm_f16_pp<2, 4, 8, 5, false, 2, true>', 'FF-out 65536x320x(1280+320 folded proj_out) + residual, ping-pong 256x320 tile', None, 65536 * 1600 * 2 + 2 * 65536 * 320 * 2 + 320 * 1600 * 2),
     ('k_gemm_f16_dmap<256, 256, false, 4, false, 4, 6>', 'level-0 GEGLU 65536x2560x320 with the LayerNorm fold, 256x256 tile', None, 65536 * 320 * 2 + 65536 * 1280 * 2 + 2560 * 320 * 2),
     ('k_gemm_f16_pp<2, 4, 8, 5, true, 10, false>', '16x16-level conv3x3 M 4096 N 1280 K 11520, ping-pong 256x320 tiles x split-K 4 (fp32 slabs)', None, 4096 * 1280 * 2 * 2 + 1280 * 11520 * 2),
-    ('k_gemm_f16_dma<256, 160, true, 8, false, 2, 2, 0>', '8x8-level conv3x3 M 1024 N 1280 K 11520, 256x160 tiles x split-K 8 (fp32 slabs)', None, 1024 * 1280 * 2 * 2 + 1280 * 11520 * 2),
+    ('k_gemm_f16_pp<2, 4, 4, 5, true, 10, false>', '8x8-level conv3x3 M 1024 N 1280 K 11520, ping-pong 128x320 tiles x split-K 8 (fp32 slabs)', None, 1024 * 1280 * 2 * 2 + 1280 * 11520 * 2),
     ('k_splitk_finish', 'split-K finish launches (fp32 slabs -> fp16)', None, 0),
 ]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
