@@ -1231,8 +1231,9 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     // (+13..14 %).  Convolutions with the ResBlock shortcut appended (their A2 rows stream from HBM inside a few K-tiles),
     // GEGLU and the short-K projections stay on the 2-barrier kernels (equal or faster there); FD_GEMM_PP=0 switches the rule off.
     if (g_pp && g_use_dma && g_fast_epi && g_bias_lds && !geglu && !d->ln_stats_out && (!g.ln_stats || g.mode != MODE_CONV) && (batch == 1 || g.phase) && !g.out_f32 &&
-        g.act == FD_ACT_NONE && g.N % 320 == 0 && g.M % 128 == 0 && (g.ldc & 7) == 0 && (!g.res || (g.ldr & 3) == 0) &&
-        (!g.bias2 || g.rows_per_batch % 256 == 0)) {
+        g.act == FD_ACT_NONE && g.N % 320 == 0 && g.M % 128 == 0 && (g.ldc & 7) == 0 && (!g.res || (g.ldr & 3) == 0)) {
+        // (the lean epilogue takes a per-sample bias only from tiles that lie in one sample; split-K launches leave it to the finish kernel)
+        const bool b2ok = !g.bias2 || g.rows_per_batch % 256 == 0;
         // (the parity-decomposed upsample convolution is four launch slices -- blockIdx.z -- of the same tile grid: no split-K there)
         const long long t30 = (g.M % 256 == 0 ? (long long)(g.M / 256) * (g.N / 320) : 0) * batch, t32 = (long long)(g.M / 128) * (g.N / 320) * batch;
         int tile = 0, split = 1;
@@ -1247,12 +1248,12 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
                     split *= 2;
                 if (t30 * split >= 200 && fd_round_eff(t30 * split, 256) >= 0.85) tile = 30;
                 // two K slices of a short K loop lose to whole 128x320 tiles (the slab round trip + finish launch are fixed costs)
-                if (tile == 30 && split == 2 && nk_all < 150 && t32 >= 200 && fd_round_eff(t32, 256) >= 0.85) {
+                if (tile == 30 && split == 2 && nk_all < 150 && b2ok && t32 >= 200 && fd_round_eff(t32, 256) >= 0.85) {
                     tile = 32;
                     split = 1;
                 }
             }
-            if (!tile && t32 >= 200 && fd_round_eff(t32, 256) >= 0.85) tile = 32, split = 1;
+            if (!tile && b2ok && t32 >= 200 && fd_round_eff(t32, 256) >= 0.85) tile = 32, split = 1;
             // few rows, long K (the 8x8 level: 1024 x 1280 x 11520 / 23040): 128x320 tiles x up to 8 K slices -- 44.4 vs 46.0 / 66.8 vs 71.4 us
             // against 256x160 x 8 on the 2-barrier kernel (4 launches each, profiles/r05_gemm_sweep_vae.txt header run)
             if (!tile && t32 > 0) {
@@ -1268,6 +1269,7 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
             if (t30 >= 200 && fd_round_eff(t30, 256) >= 0.85) tile = 30;
             else if (t32 >= 200 && fd_round_eff(t32, 256) >= 0.85) tile = 32;
         }
+        if (split == 1 && !b2ok) tile = 0;
         if (tile) {
             g.split_k = split;
             if (fd_gemm_pp_ok(g, batch, tile)) {
