@@ -1423,3 +1423,51 @@ def test_vae_decode_in_sample_chunks_and_large_gemm_fallback(mini, dev):
     rows = torch.tensor([0, 12345, M // 2 + 7, M - 1], device=dev)
     want = a[rows].float() @ w.w[:, :K].float().t()
     assert float((out[rows].float() - want).abs().max()) < 2e-2 * float(want.abs().max())
+
+
+def test_full_size_checkpoint_from_disk_equals_in_memory_build(sd15, dev, tmp_path):
+    '''The from-disk path at FULL size (the oracle-checked from-disk test above runs at mini size): the 859.5 M-parameter
+    UNet, the VAE and CLIP ViT-L/14 are written as fp32 safetensors in the diffusers / CLIPModel directory layout (5.5 GB, what
+    CompVis/stable-diffusion-v1-4 + openai/clip-vit-large-patch14 look like on disk), read back through `FlexPipeline.from_pretrained` (reference
+    utils.py:59-71), and the same request -- 256x256, 10 DDIM steps, CFG 8: BASELINE configs[0], whose in-memory build is oracle-checked by
+    test_sd15_c1_pipeline_psnr -- must give the same images bit for bit; CLIP text and image features likewise.'''
+    import json
+    import shutil
+    from safetensors.torch import save_file
+    from flexdiffuse_amd import FlexPipeline, SimpleGuide, build
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    from flexdiffuse_amd.tokenizer import CLIPBPETokenizer
+    from test_oracle_clip import synth_image
+    from test_tokenizer import toy_vocab
+    sds, pipe, clip, tok, (ucfg, vcfg, ccfg) = sd15
+    sd_dir, clip_dir = tmp_path / 'stable-diffusion', tmp_path / 'clip'
+    try:
+        for sub in ('unet', 'vae', 'tokenizer'):
+            os.makedirs(sd_dir / sub)
+        os.makedirs(clip_dir)
+        save_file({k: v.contiguous() for k, v in sds['unet'].items()}, str(sd_dir / 'unet' / 'diffusion_pytorch_model.safetensors'))
+        save_file({k: v.contiguous() for k, v in sds['vae'].items()}, str(sd_dir / 'vae' / 'diffusion_pytorch_model.safetensors'))
+        save_file({k: v.contiguous() for k, v in sds['clip'].items()}, str(clip_dir / 'model.safetensors'))
+        on_disk = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(tmp_path) for f in fs)
+        assert on_disk > 4e9, on_disk
+        vocab, merges = toy_vocab()
+        (sd_dir / 'tokenizer' / 'vocab.json').write_text(json.dumps(vocab), encoding='utf-8')
+        (sd_dir / 'tokenizer' / 'merges.txt').write_text('#version: 0.2\n' + '\n'.join(' '.join(m) for m in merges) + '\n', encoding='utf-8')
+        p2, clip2, tok2 = build.from_directories(str(sd_dir), str(clip_dir), preset='sd15', device=dev, vae_encoder=False)
+    finally:
+        shutil.rmtree(tmp_path, ignore_errors=True)
+    assert isinstance(p2, FlexPipeline) and isinstance(tok2, CLIPBPETokenizer) and p2.tokenizer is tok2 and type(p2.scheduler).__name__ == 'DDIMScheduler'
+    enc, enc2 = CLIPEncoder(clip, tok), CLIPEncoder(clip2, tok2)
+    # CLIP from disk: same ids through both text towers, same pixels through both vision towers
+    ids = tok('a photo of a turtle in a forest, oil painting').input_ids.to(dev)
+    assert torch.equal(clip.text_model(ids)[0], clip2.text_model(ids)[0])
+    img = synth_image(4, 224, 224)
+    assert torch.equal(enc.image(img), enc2.image(img))
+    # UNet + VAE from disk: the c1 request with the same embeddings and noise
+    emb = enc.prompt('a photo of a turtle in a forest, oil painting')
+    outs = []
+    for pp_, e_ in ((pipe, enc), (p2, enc)):
+        pp_(guide=SimpleGuide(e_, pp_.unet, 8.0, 10, emb), init_size=(256, 256), generator=torch.Generator('cpu').manual_seed(1337), output_type='np')
+        outs.append((pp_.last_latents.clone(), pp_.last_images.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].float().std()) > 0.02
