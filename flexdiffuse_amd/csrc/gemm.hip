@@ -996,11 +996,29 @@ extern "C" int fd_gemm_can_emit_row_stats(int M, int N, int K, int ldc, int ldr)
     return fd_stats_plan(M, N, &tile);   // slabs of partial sums the caller must provide and finalise (1: finalised in place)
 }
 
+static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice);
+
 extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     if (fd_plan_recording() && d) {
         const fd_gemm_desc dc_ = *d;
         fd_plan_push([dc_](void* fd_s_) -> int { return fd_gemm_f16(&dc_, fd_s_); });
     }
+    return gemm_impl(d, stream, nullptr);
+}
+
+// The tile id and split-K factor fd_gemm_f16 would launch `d` with (after the same argument checks), without launching anything:
+// host logic only, no HIP call -- usable without a device (tests/test_gemm_rule_table.py pins the rule's choices on the launches
+// of the bench forward).  Pointers are only tested for NULL / alignment.
+extern "C" int fd_gemm_plan(const fd_gemm_desc* d, int* tile, int* split_k) {
+    FD_CHECK_ARG(tile && split_k, FD_EINVAL, "fd_gemm_plan: null output pointer");
+    int choice[2] = {0, 0};
+    const int rc = gemm_impl(d, nullptr, choice);
+    *tile = choice[0];
+    *split_k = choice[1];
+    return rc;
+}
+
+static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
     FD_CHECK_ARG(d && d->A && d->W && d->C, FD_EINVAL, "fd_gemm_f16: null pointer");
     FD_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, FD_EINVAL, "fd_gemm_f16: M/N/K must be > 0");
     FD_CHECK_ARG(d->K % 8 == 0 && d->ldw % 8 == 0, FD_ESHAPE,
@@ -1101,13 +1119,19 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     g.ws = (float*)d->workspace;
     int rc;
     if (d->trans_out) {
-        fd_prof_begin(FD_FAMILY_GEMM, st, flops, flops_exec);
         // 128x160 with 8 waves where 160 | N and the rows fill the chip: -16..18 % on the 64x64 / 32x32
         // self-attention V projections (tools/ab_vt.py; 256x160 / 16 waves is no better, 16x16 maps tie).
         // FD_GEMM_VT_TILE=0: the 128x64 / 4-wave tile everywhere (A/B)
         static const int vt_tile = getenv("FD_GEMM_VT_TILE") ? atoi(getenv("FD_GEMM_VT_TILE")) : 9;
-        if (vt_tile && g.N % 160 == 0 && batch == 1 && g.M >= 8192 &&
-            2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K) < 0x7fffffffull)
+        const bool vt160 = vt_tile && g.N % 160 == 0 && batch == 1 && g.M >= 8192 &&
+                           2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K) < 0x7fffffffull;
+        if (choice) {
+            choice[0] = vt160 ? 9 : 3;      // (the transposed-store forms of the 128x160 / 128x64 tiles)
+            choice[1] = 1;
+            return FD_OK;
+        }
+        fd_prof_begin(FD_FAMILY_GEMM, st, flops, flops_exec);
+        if (vt160)
             rc = g.ln_stats ? launch_mode<128, 160, true, false, 4, 2, 2, 7>(g, batch, st) : launch_mode<128, 160, true, false, 4, 2, 2, 0>(g, batch, st);
         else
         rc = g.ln_stats ? launch_mode<128, 64, true, false, 2, 2, 2, 7>(g, batch, st) : launch<128, 64, true>(g, batch, st);
@@ -1201,6 +1225,13 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     // 4096x320x1280 FF-out -- would leave 64 workgroups on 256 CUs with split-K switched off)
     if (g.mode != MODE_CONV && n160 && g.M > 2048 && g.M <= 4096 && g.K >= 1280 && batch == 1 &&
         (long long)fd_cdiv(g.M, 256) * (g.N / 160) < 256 && (long long)fd_cdiv(g.M, 128) * (g.N / 160) >= 200) {
+        best_tile = 20;
+        best_split = 1;
+    }
+    // the parity-decomposed upsample convolution of a small map (16 x 8 x 8 -> 16 x 16: four slices of 1024 rows, no split-K in this mode):
+    // 256-row tiles give 128 workgroups, the 3-stage 128x160 tile 256 -- 68 vs 90 us (tools/ab_up8.py; the fused-upsample form it replaces: 133 us)
+    if (g.phase && n160 && g.M % 128 == 0 && g.K >= 1280 && (long long)fd_cdiv(g.M, 256) * (g.N / 160) * batch < 200 &&
+        (long long)(g.M / 128) * (g.N / 160) * batch >= 200) {
         best_tile = 20;
         best_split = 1;
     }
@@ -1364,6 +1395,13 @@ extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
         FD_CHECK_ARG(fd_gemm_pp_ok(g, batch, best_tile), FD_ESHAPE,
                      "fd_gemm_f16: ping-pong tile %d cannot run M=%d N=%d K=%d (full tiles, K %% 64 == 0, conv: Wo %% 8 == 0, no fused upsample)",
                      best_tile, g.M, g.N, g.K);
+    if (g.ln_stats && !(best_tile == 9 || best_tile == 10 || (best_tile >= 12 && best_tile <= 16) || best_tile == 20 || best_tile == 23 || best_tile >= 30))
+        best_tile = best_tile == 4 ? 4 : -7;     // (reported by fd_gemm_plan as -7: the 128x128 generic kernel with the fold compiled in)
+    if (choice) {
+        choice[0] = best_tile;
+        choice[1] = best_split;
+        return FD_OK;
+    }
     fd_prof_begin(FD_FAMILY_GEMM, st, flops, flops_exec);
     if (g.ln_stats && !(best_tile == 9 || best_tile == 10 || (best_tile >= 12 && best_tile <= 16) || best_tile == 20 || best_tile == 23 || best_tile >= 30)) {
         // small problems: the generic epilogue with the fold compiled in (64x64 for few rows)

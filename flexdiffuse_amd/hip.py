@@ -46,6 +46,7 @@ _SIGNATURES = {
     'fd_guidance_header_pull': (c_int, [P, P, c_int, c_int, c_int, P]),
     'fd_gemm_f16': (c_int, [P, P]),
     'fd_gemm_can_emit_row_stats': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'fd_gemm_plan': (c_int, [c_void_p, c_void_p, c_void_p]),
     'fd_attention_f16': (c_int, [P, P]),
     'fd_xattn_image_bytes': (c_int64, [c_int, c_int]),
     'fd_xattn_pack_kv_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, P]),

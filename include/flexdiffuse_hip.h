@@ -224,6 +224,11 @@ int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);
  * or 0) with the library's current settings: 1 = the finished (rstd, -mean rstd) pairs, k > 1 = k slabs of partial
  * sums for fd_ln_finalize_stats_f32; 0: run fd_ln_row_stats_f16 on the output instead. */
 int fd_gemm_can_emit_row_stats(int M, int N, int K, int ldc, int ldr);
+/* The tile id and split-K factor fd_gemm_f16 would launch `d` with -- the same argument checks and cost model (reference call
+ * site: every linear / convolution behind pipeline/guide.py:56-58), nothing launched, no HIP call: usable without a device.
+ * Tile ids as in fd_gemm_desc.tile (30..33: the ping-pong kernels of gemm_pp.hip; -7: the 128x128 generic kernel with the
+ * LayerNorm fold compiled in).  Pointers are only tested for NULL / alignment. */
+int fd_gemm_plan(const fd_gemm_desc* d, int* tile, int* split_k);
 
 /* Flash attention forward (scores never leave registers).  Q [B][n_q][ldq], K [B][n_k][ldk]
  * with head h at column h*head_dim; Vt [B][heads*head_dim][ldvt] is V transposed (keys

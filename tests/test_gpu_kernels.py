@@ -714,7 +714,7 @@ def test_gemm_with_appended_operand_folds_two_linears(dev, M, C):
 
 
 @pytest.mark.parametrize('B,H,Cin,Cout', [(16, 32, 640, 640), (16, 16, 1280, 1280), (2, 64, 512, 512), (1, 128, 256, 256),
-                                          (4, 32, 128, 128)])
+                                          (4, 32, 128, 128), (16, 8, 1280, 1280), (16, 12, 1280, 1280)])   # (the last two: 1024 / 2304 rows, round 5)
 def test_upsample_conv_phase_decomposition(dev, B, H, Cin, Cout):
     '''fd_gemm_desc.upsample2x == 2: nearest-2x upsample + conv3x3 (diffusers Upsample2D) as four 2x2 parity convolutions
     of the low-resolution input in one launch (4/9 of the MACs) vs (a) torch fp32 F.interpolate + conv2d and (b) the
@@ -740,7 +740,8 @@ def test_upsample_conv_phase_decomposition(dev, B, H, Cin, Cout):
     assert float((gotf - old).abs().max()) <= tol
     assert float((gotf - want).abs().mean()) <= 1.2 * float((old - want).abs().mean()) + 1e-5
     assert float(buf[:, Cout:].abs().max()) == 0.0           # nothing written past the view
-    assert not ops.up_phases_supported(1024, Cout, Cin)      # too few rows: stays on the fused-upsample conv
+    assert not ops.up_phases_supported(512, Cout, Cin)       # too few rows: stays on the fused-upsample conv
+    assert not ops.up_phases_supported(1024, 512, 512) and ops.up_phases_supported(1024, 1280, 1280)   # (VAE widths: from 4096 rows)
 
 
 @pytest.mark.parametrize('M,N,K,res', [(16384, 640, 640, True), (4096, 1280, 1280, True), (4096, 1280, 1280, False),
