@@ -185,9 +185,47 @@ def parity_c2(sds, cfgs, pipe, guide_ctx, enc):
             'tolerance': 'PSNR >= 40 dB'}
 
 
-# sampling stride of the per-launch HIP events: coprime with the launch pattern of a UNet step
-# (220 GEMM, 33 attention, 61 GroupNorm launches), so over 50 steps every shape is visited
-EVENT_STRIDE = 7
+# Every launch of the roofline leg is bracketed (stride 1): the leg replays the recorded launch plan, so a bracket costs
+# stream time only in that untimed pass.  FD_BENCH_EVENT_STRIDE=n samples every n-th launch of a family instead.
+EVENT_STRIDE = max(1, int(os.environ.get('FD_BENCH_EVENT_STRIDE', '1')))
+FAMILY_NAMES = {0: 'gemm', 1: 'attention', 2: 'groupnorm', 3: 'other_kernels'}
+
+
+def aggregate_brackets(fam, tag, ms, work, executed, empty_ms, stride=1):
+    '''Per kernel family, from the individual event brackets of one pass (flexdiffuse_amd.hip.prof_drain):
+    the brackets are grouped by (family, tag, declared work) -- one group = one launch shape -- and a group contributes
+    MEDIAN(bracket) - empty bracket, times its launch count: a host stall that lands between an event record and its
+    launch (round 5: one 39 ms stall, scaled by the sampling stride, became 273 ms of "GroupNorm") moves one bracket of
+    one group and leaves the median where it was.  `raw_ms` keeps the plain sum for comparison.'''
+    import numpy as np
+    out = {}
+    fam, tag, ms, work, executed = (np.asarray(a) for a in (fam, tag, ms, work, executed))
+    for code, name in FAMILY_NAMES.items():
+        sel = fam == code
+        rec = {'ms': 0.0, 'raw_ms': float(ms[sel].sum()) * stride, 'work': float(work[sel].sum()) * stride,
+               'executed': float(executed[sel].sum()) * stride, 'launches': int(sel.sum()) * stride, 'groups': 0,
+               'worst_bracket_over_median': 1.0}
+        keys = {}
+        for i in np.nonzero(sel)[0]:
+            keys.setdefault((int(tag[i]), float(work[i])), []).append(float(ms[i]))
+        for v in keys.values():
+            med = float(np.median(v))
+            rec['ms'] += max(med - empty_ms, 0.0) * len(v) * stride
+            if med > 0:
+                rec['worst_bracket_over_median'] = max(rec['worst_bracket_over_median'], max(v) / med)
+        rec['groups'] = len(keys)
+        out[name] = rec
+    return out
+
+
+def time_budget(fams, ms_per_step):
+    '''Where a step's wall time goes, summing to ms_per_step by construction: the four kernel families of the roofline
+    leg and the remainder (launch gaps on the device, torch's own fill / copy kernels, the device->host copy of the
+    images, host work the device waits for).  `valid` is False when the families alone exceed the step.'''
+    b = {k: fams[k]['ms'] for k in ('gemm', 'attention', 'groupnorm', 'other_kernels')}
+    kernels = sum(b.values())
+    b['gaps_and_host'] = ms_per_step - kernels
+    return b, kernels <= ms_per_step
 
 
 def best_kernel_leg(dev):
@@ -591,24 +629,36 @@ def main():
                   'note': 'issue time of 5 back-to-back CFG UNet forwards vs their completion time'}
         margin['host_over_device'] = margin['host_ms_per_forward'] / margin['device_ms_per_forward']
 
-    # ---- roofline leg: one extra UNTIMED pass with HIP events on the launch stream around every
-    # EVENT_STRIDE-th launch of each kernel family (a pair of event records costs stream time, so
-    # it stays out of `elapsed`); the cost of an empty bracket is measured and subtracted.
-    fam, empty_ms = {}, 0.0
+    # ---- roofline leg: one extra UNTIMED pass with a pair of HIP events on the launch stream around every launch of
+    # the library (the four families of FD_FAMILY_*).  Same launch mode as the timed region: where that replays a HIP
+    # graph the leg replays the recorded LAUNCH PLAN -- the same kernels, tiles and order issued by one host call per
+    # forward -- instead of the eager Python front (round 5's leg, whose host stalls ended up inside brackets).
+    # Aggregation: median per launch shape x count (aggregate_brackets).  If the families still do not fit in the step
+    # the leg is run once more (`roofline_retries`); `roofline_valid` says whether the final numbers fit.
+    fams, empty_ms, roofline_retries, roofline_valid = None, 0.0, 0, False
+    ms_per_step = 1e3 * elapsed / args.steps
     if rank == 0:
-        empty_ms = hip.prof_calibrate(256)
-        hip.prof_set_stride(EVENT_STRIDE)
-        hip.prof_enable(True)
-        one_pass(time_gather=True)
+        was_graph, was_plan = pipe.use_graph, pipe.use_plan
+        if pipe.use_graph:
+            pipe.use_graph, pipe.use_plan = False, True
+        one_pass()                        # records the plan (and warms the mode) with the recorder off
         torch.cuda.synchronize()
-        hip.prof_enable(False)
-        for name, code in (('gemm', ops.FAMILY_GEMM), ('attention', ops.FAMILY_ATTENTION),
-                           ('groupnorm', ops.FAMILY_GROUPNORM)):
-            ms, work, executed, n = hip.prof_collect2(code)
-            fam[name] = {'ms': max(ms - n * empty_ms, 0.0), 'raw_ms': ms, 'work': work, 'executed': executed,
-                         'launches': n}
+        for attempt in range(2):
+            empty_ms = hip.prof_calibrate(256)
+            hip.prof_set_stride(EVENT_STRIDE)
+            hip.prof_enable(True)
+            one_pass(time_gather=(attempt == 0))
+            torch.cuda.synchronize()
+            hip.prof_enable(False)
+            fams = aggregate_brackets(*hip.prof_drain(), empty_ms, EVENT_STRIDE)
+            _, roofline_valid = time_budget(fams, ms_per_step)
+            roofline_retries = attempt
+            if roofline_valid:
+                break
+        pipe.use_graph, pipe.use_plan = was_graph, was_plan
     elif dist.is_initialized():
-        one_pass(time_gather=True)       # every rank takes part in the extra pass's all-gather
+        one_pass()
+        one_pass(time_gather=True)       # every rank takes part in the extra passes' all-gathers
         torch.cuda.synchronize()
 
     import resource
@@ -621,11 +671,11 @@ def main():
     if rank == 0:
         images = B * N * args.steps
         value = images / elapsed
-        ms_per_step = 1e3 * elapsed / args.steps
-        g, att, gn = fam['gemm'], fam['attention'], fam['groupnorm']
+        g, att, gn = fams['gemm'], fams['attention'], fams['groupnorm']
         achieved = (g['work'] / (g['ms'] * 1e-3)) / 1e12 if g['ms'] > 0 else 0.0
         executed = (g['executed'] / (g['ms'] * 1e-3)) / 1e12 if g['ms'] > 0 else 0.0
-        fam_sum = EVENT_STRIDE * (g['ms'] + att['ms'] + gn['ms'])
+        budget, _ = time_budget(fams, ms_per_step)
+        fam_sum = g['ms'] + att['ms'] + gn['ms']
         # HBM bytes of the dominant kernel (level-0 conv3x3) from its PMC pass: rocprofv3 cannot
         # run inside this process, so the committed per-launch measurement is reported with its
         # source (it is NOT re-measured by this run)
@@ -676,21 +726,29 @@ def main():
                 # false only when the PMC record was collected on exactly these GEMM sources (sha256 recorded with it)
                 'traffic_stale': traffic_stale,
                 'traffic_other_kernels': traffic_other,
-                # sums over the sampled launches (every EVENT_STRIDE-th of each family) of one
-                # untimed pass, empty-bracket cost subtracted, scaled to the pass
-                'sampled_every': EVENT_STRIDE, 'sampled_launches': g['launches'],
-                'launches': g['launches'] * EVENT_STRIDE,
+                # one untimed pass in the timed region's launch mode (graph -> the recorded launch plan), every launch
+                # bracketed by HIP events on its stream; per launch shape MEDIAN bracket - empty bracket, x launch count
+                'leg_launch': 'plan' if margin['launch'] == 'graph' else margin['launch'],
+                'aggregation': 'median per (family, launch shape) x launches',
+                'sampled_every': EVENT_STRIDE, 'sampled_launches': g['launches'] // EVENT_STRIDE,
+                'launches': g['launches'], 'launch_shapes': g['groups'],
                 'empty_bracket_us': 1e3 * empty_ms,
-                'kernel_ms_per_pass': g['ms'] * EVENT_STRIDE,
+                'kernel_ms_per_pass': g['ms'], 'kernel_ms_per_pass_plain_sum': g['raw_ms'] - g['launches'] * empty_ms,
                 'avg_launch_us': 1e3 * g['ms'] / g['launches'] if g['launches'] else None,
                 'attention_tflops': (att['work'] / (att['ms'] * 1e-3)) / 1e12 if att['ms'] else 0.0,
-                'attention_ms_per_pass': att['ms'] * EVENT_STRIDE,
+                'attention_ms_per_pass': att['ms'],
                 # GroupNorm priced at SURVEY 8(d)'s 4 B/element (fp16 read + write)
                 'groupnorm_gbps': (gn['work'] / (gn['ms'] * 1e-3)) / 1e9 if gn['ms'] else 0.0,
                 'groupnorm_frac_of_hbm': ((gn['work'] / (gn['ms'] * 1e-3)) / 1e9 / HBM_PEAK_GBPS) if gn['ms'] else 0.0,
-                'groupnorm_ms_per_pass': gn['ms'] * EVENT_STRIDE,
+                'groupnorm_ms_per_pass': gn['ms'],
+                'other_kernels_ms_per_pass': fams['other_kernels']['ms'],
                 'families_ms_per_pass': fam_sum,
                 'families_fit_in_step': fam_sum <= ms_per_step,
+                # sums to ms_per_step: the four families of library launches + everything else (device-side launch gaps,
+                # torch's fill / copy kernels, the device->host copy of the images, host work the device waits for)
+                'time_budget_ms': budget,
+                'roofline_valid': roofline_valid, 'roofline_retries': roofline_retries,
+                'worst_bracket_over_median': {k: v['worst_bracket_over_median'] for k, v in fams.items()},
                 'end_to_end_frac_of_mfma_roofline':
                     (value / N) * fpi / (MFMA_PEAK_TFLOPS * 1e12) if fpi else None,
             },

@@ -186,15 +186,25 @@ def load_scheduler(sd_dir: str, prediction_type: str = 'epsilon'):
     with open(path, encoding='utf-8') as f:
         cfg = json.load(f)
     name = cfg.get('_class_name', 'PNDMScheduler')
-    common = {k: cfg[k] for k in ('num_train_timesteps', 'beta_start', 'beta_end', 'beta_schedule') if k in cfg}
+    # keys the file does not carry take DIFFUSERS' defaults (the class the reference would instantiate from this file:
+    # linear betas 1e-4 .. 0.02, skip_prk_steps False), not this package's SD presets
+    common = {'num_train_timesteps': cfg.get('num_train_timesteps', 1000), 'beta_start': cfg.get('beta_start', 0.0001),
+              'beta_end': cfg.get('beta_end', 0.02), 'beta_schedule': cfg.get('beta_schedule', 'linear')}
+    ptype = cfg.get('prediction_type', prediction_type)
+    if name in ('PNDMScheduler', 'LMSDiscreteScheduler') and ptype != 'epsilon':
+        # neither class has v-prediction arithmetic here: stepping a v-prediction UNet (SD2.1) as epsilon would be a
+        # silently wrong image
+        raise NotImplementedError(f'{path}: {name} with prediction_type {ptype!r} is not provided (epsilon only); pass '
+                                  'scheduler=DDIMScheduler(prediction_type=...) to choose one explicitly')
     if name == 'PNDMScheduler':
-        extra = {k: cfg[k] for k in ('skip_prk_steps', 'steps_offset') if k in cfg}
+        extra = {'skip_prk_steps': cfg.get('skip_prk_steps', False), 'steps_offset': cfg.get('steps_offset', 0)}
         return PNDMScheduler(**common, **extra)
     if name == 'LMSDiscreteScheduler':
         return LMSDiscreteScheduler(**common)
     if name == 'DDIMScheduler':
-        extra = {k: cfg[k] for k in ('clip_sample', 'set_alpha_to_one', 'steps_offset') if k in cfg}
-        return DDIMScheduler(**common, **extra, prediction_type=cfg.get('prediction_type', prediction_type))
+        extra = {'clip_sample': cfg.get('clip_sample', True), 'set_alpha_to_one': cfg.get('set_alpha_to_one', True),
+                 'steps_offset': cfg.get('steps_offset', 0)}
+        return DDIMScheduler(**common, **extra, prediction_type=ptype)
     raise NotImplementedError(f'{path}: scheduler class {name!r} is not provided (PNDMScheduler, LMSDiscreteScheduler, '
                               'DDIMScheduler are); pass scheduler= to choose one explicitly')
 

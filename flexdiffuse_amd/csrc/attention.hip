@@ -917,7 +917,7 @@ extern "C" int fd_attention_f16(const fd_attention_desc* d, void* stream) {
     dim3 grid(fd_cdiv(d->n_q, 128) * d->heads * d->batch);
     const double flops = 4.0 * (double)d->batch * d->heads * (double)d->n_q * d->n_k * d->head_dim *
                          (d->causal ? 0.5 : 1.0);
-    fd_prof_begin(FD_FAMILY_ATTENTION, st, flops);
+    fd_prof_begin(FD_FAMILY_ATTENTION, st, flops, -1.0, fd_tag(6u, d->batch * d->heads, d->n_q, d->n_k, d->head_dim));
     const int hd = d->head_dim;
     // FD_ATTN_QT1: 0 = 4-wave / 32-query kernel, 1 = 8-wave kernel with the exact running max,
     // 2 (default) = 8-wave kernel with the VALU-lean softmax (lazy max, fused denominator)

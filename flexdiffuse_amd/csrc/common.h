@@ -54,8 +54,39 @@ void fd_plan_push(std::function<int(void*)> op);
 // optional per-launch HIP-event timing of a kernel family (bench.py roofline leg)
 // `work`: the ALGORITHMIC FLOPs / bytes of the op the launch implements; `executed` (< 0: same as work): what the
 // kernel really issues (the parity-decomposed upsample convolution runs 4/9 of its 3x3 MACs)
-void fd_prof_begin(int family, hipStream_t s, double work, double executed = -1.0);
+// `tag`: an identity of the launch's shape / kernel choice (0 = none): bench.py groups the sampled brackets by
+// (family, tag, work) and takes each group's MEDIAN, so one host stall inside one bracket cannot move a family's sum
+void fd_prof_begin(int family, hipStream_t s, double work, double executed = -1.0, unsigned tag = 0);
 void fd_prof_end(int family, hipStream_t s);
+#ifdef __cplusplus
+// bracket of one entry point of the FD_FAMILY_OTHER kind (layout / elementwise / LayerNorm / guidance launches): closes on
+// every return path
+struct FdProfScope {
+    int family;
+    hipStream_t st;
+    FdProfScope(int f, void* stream, double bytes, unsigned tag = 0) : family(f), st((hipStream_t)stream) { fd_prof_begin(f, st, bytes, -1.0, tag); }
+    ~FdProfScope() { fd_prof_end(family, st); }
+};
+static inline unsigned fd_tag(unsigned a, unsigned b = 0, unsigned c = 0, unsigned d = 0, unsigned e = 0, unsigned f = 0) {
+    unsigned h = 2166136261u;
+    const unsigned v[6] = {a, b, c, d, e, f};
+    for (int i = 0; i < 6; ++i) h = (h ^ v[i]) * 16777619u;
+    return h | 1u;
+}
+#endif
+
+#ifdef __cplusplus
+#include <atomic>
+// One-time per-(kernel instantiation, DEVICE) setup such as hipFuncSetAttribute(MaxDynamicSharedMemorySize): a function
+// attribute belongs to the device's copy of the code object, so a process that drives a second GPU must set it there too.
+// `mask` is a static of the instantiation; true exactly once per device (thread-safe).
+static inline bool fd_first_on_device(std::atomic<unsigned long long>* mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    const unsigned long long bit = 1ull << (dev & 63);
+    return (mask->fetch_or(bit) & bit) == 0;
+}
+#endif
 
 typedef _Float16 half_t;
 typedef half_t half8 __attribute__((ext_vector_type(8)));

@@ -23,6 +23,7 @@ __global__ void k_nchw_to_nhwc(const float* __restrict__ x, half_t* __restrict__
 extern "C" int fd_nchw_f32_to_nhwc_f16(const float* x, void* y, int B, int C, int HW, int rep,
                                        int c_pad, float scale, void* stream) {
     FD_PLAN(fd_nchw_f32_to_nhwc_f16(x, y, B, C, HW, rep, c_pad, scale, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(x && y && B > 0 && C > 0 && HW > 0 && rep > 0 && c_pad >= C, FD_EINVAL,
                  "fd_nchw_f32_to_nhwc_f16: args");
     const size_t total = (size_t)B * HW * c_pad;
@@ -52,6 +53,7 @@ __global__ void k_nhwc_to_nchw(const float* __restrict__ x, float* __restrict__ 
 extern "C" int fd_nhwc_f32_to_nchw_f32(const float* x, float* y, int B, int C, int HW, int ld,
                                        float a, float b, int clamp01, void* stream) {
     FD_PLAN(fd_nhwc_f32_to_nchw_f32(x, y, B, C, HW, ld, a, b, clamp01, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(x && y && B > 0 && C > 0 && HW > 0 && ld >= C, FD_EINVAL,
                  "fd_nhwc_f32_to_nchw_f32: args");
     const size_t total = (size_t)B * C * HW;
@@ -92,6 +94,7 @@ extern "C" int fd_im2col_f16(const void* x, void* y, int B, int Hi, int Wi, int 
                              int Wo, int KH, int KW, int stride, int pad_t, int pad_l, int k_pad,
                              void* stream) {
     FD_PLAN(fd_im2col_f16(x, y, B, Hi, Wi, Cin, Ho, Wo, KH, KW, stride, pad_t, pad_l, k_pad, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Ho > 0 && Wo > 0, FD_EINVAL,
                  "fd_im2col_f16: args");
     FD_CHECK_ARG(k_pad >= KH * KW * Cin && k_pad % 8 == 0, FD_ESHAPE, "fd_im2col_f16: k_pad");
@@ -119,6 +122,7 @@ __global__ void k_concat(const uint4* __restrict__ a, const uint4* __restrict__ 
 extern "C" int fd_concat_channels_f16(const void* a, const void* b, void* out, int64_t M, int Ca,
                                       int Cb, void* stream) {
     FD_PLAN(fd_concat_channels_f16(a, b, out, M, Ca, Cb, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(a && b && out && M > 0, FD_EINVAL, "fd_concat_channels_f16: args");
     FD_CHECK_ARG(Ca % 8 == 0 && Cb % 8 == 0, FD_ESHAPE, "fd_concat_channels_f16: C %% 8");
     const size_t total = (size_t)M * (Ca + Cb) / 8;
@@ -146,6 +150,7 @@ __global__ void k_copy2d(const uint4* __restrict__ src, size_t lds8, uint4* __re
 extern "C" int fd_copy2d_f16(const void* src, int lds, void* dst, int ldd, int64_t rows, int cols,
                              void* stream) {
     FD_PLAN(fd_copy2d_f16(src, lds, dst, ldd, rows, cols, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, FD_EINVAL,
                  "fd_copy2d_f16: args");
     FD_CHECK_ARG(cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && (uintptr_t)src % 16 == 0 &&
@@ -201,6 +206,7 @@ extern "C" int fd_cfg_ddim_step_f32(float* x, const float* eps_nhwc, float* eps_
                                     float c3, float c4, int v_prediction, int do_step,
                                     void* stream) {
     FD_PLAN(fd_cfg_ddim_step_f32(x, eps_nhwc, eps_out, B, C, HW, ld, cfg, guidance, c1, c2, c3, c4, v_prediction, do_step, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(eps_nhwc && B > 0 && C > 0 && HW > 0 && ld >= C, FD_EINVAL,
                  "fd_cfg_ddim_step_f32: args");
     FD_CHECK_ARG(!do_step || x, FD_EINVAL, "fd_cfg_ddim_step_f32: x is null");
@@ -227,6 +233,7 @@ __global__ void k_axpby(const float* __restrict__ x, const float* __restrict__ y
 extern "C" int fd_axpby_f32(const float* x, const float* y, float* out, int64_t n, float a,
                             float b, int exp_half_x, void* stream) {
     FD_PLAN(fd_axpby_f32(x, y, out, n, a, b, exp_half_x, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(x && out && n > 0, FD_EINVAL, "fd_axpby_f32: args");
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_axpby, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, out,
@@ -252,6 +259,7 @@ __global__ void k_embed_tokens(const long long* __restrict__ ids, const half_t* 
 extern "C" int fd_embed_tokens_f16(const int64_t* ids, const void* tok_emb, const void* pos_emb,
                                    void* out, int B, int L, int D, int vocab, void* stream) {
     FD_PLAN(fd_embed_tokens_f16(ids, tok_emb, pos_emb, out, B, L, D, vocab, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(ids && tok_emb && pos_emb && out && B > 0 && L > 0 && D > 0, FD_EINVAL,
                  "fd_embed_tokens_f16: args");
     hipLaunchKernelGGL(k_embed_tokens, dim3(B * L), dim3(256), 0, (hipStream_t)stream,
@@ -276,6 +284,7 @@ __global__ void k_vit_assemble(const half_t* __restrict__ patches, const half_t*
 extern "C" int fd_vit_assemble_f16(const void* patches, const void* cls, const void* pos, void* out,
                                    int B, int T, int D, void* stream) {
     FD_PLAN(fd_vit_assemble_f16(patches, cls, pos, out, B, T, D, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(patches && cls && pos && out && B > 0 && T > 1 && D > 0, FD_EINVAL,
                  "fd_vit_assemble_f16: args");
     hipLaunchKernelGGL(k_vit_assemble, dim3(B * T), dim3(256), 0, (hipStream_t)stream,
@@ -302,6 +311,7 @@ __global__ void k_timestep_embedding(const float* __restrict__ t, int t_stride, 
 extern "C" int fd_timestep_embedding_f16(const float* t, int t_stride, void* out, int B, int dim,
                                          void* stream) {
     FD_PLAN(fd_timestep_embedding_f16(t, t_stride, out, B, dim, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(t && out && B > 0 && dim > 0 && dim % 2 == 0 && (t_stride == 0 || t_stride == 1),
                  FD_EINVAL, "fd_timestep_embedding_f16: args");
     hipLaunchKernelGGL(k_timestep_embedding, dim3(B), dim3(256), 0, (hipStream_t)stream, t, t_stride,
@@ -319,6 +329,7 @@ __global__ void k_cast(const float* __restrict__ x, half_t* __restrict__ y, size
 
 extern "C" int fd_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream) {
     FD_PLAN(fd_cast_f32_to_f16(x, y, n, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(x && y && n > 0, FD_EINVAL, "fd_cast_f32_to_f16: args");
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_cast, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (half_t*)y,
@@ -335,6 +346,7 @@ __global__ void k_cast_back(const half_t* __restrict__ x, float* __restrict__ y,
 
 extern "C" int fd_cast_f16_to_f32(const void* x, float* y, int64_t n, void* stream) {
     FD_PLAN(fd_cast_f16_to_f32(x, y, n, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(x && y && n > 0, FD_EINVAL, "fd_cast_f16_to_f32: args");
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_cast_back, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
@@ -359,6 +371,7 @@ __global__ void k_region_blend(float* __restrict__ dst, const float* __restrict_
 extern "C" int fd_region_blend_f32(float* dst, const float* src, int C, int H, int W, int oy, int ox,
                                    int sh, int sw, float blend, void* stream) {
     FD_PLAN(fd_region_blend_f32(dst, src, C, H, W, oy, ox, sh, sw, blend, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
     FD_CHECK_ARG(dst && src && C > 0 && H > 0 && W > 0, FD_EINVAL, "fd_region_blend_f32: args");
     // the host resolves Python's slice semantics (a negative start counts from the end of the
     // axis: composition/guide.py:86-98) before calling; here only the clip at the far edge remains

@@ -836,14 +836,13 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
              : 2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K);
     const unsigned long long w_bytes = 2ull * ((unsigned long long)(g.N - 1) * g.ldw + g.K + g.K2);
     if (g_use_dma && a_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull) {
-        static bool configured = false;
-        if (!configured && lds > 64 * 1024) {
+        static std::atomic<unsigned long long> configured{0};
+        if (lds > 64 * 1024 && fd_first_on_device(&configured)) {
             FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV, WM, TRANS, NS, WN, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if constexpr (BN != 320)   // the 256x320 tile has no persistent form (it would spill)
                 FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS, WN, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured = true;
         }
         // Short K loops: persistent workgroups (<= 256 CUs x co-resident workgroups) walk the
         // tile list with the next tile's first K-tile prefetched under the epilogue.
@@ -885,12 +884,10 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         fd_set_error("fd_gemm_f16: 8-wave tiles need the LDS-DMA path (tensor < 2 GiB)");
         return FD_ESHAPE;
     } else {
-        static bool configured = false;
-        if (!configured && lds > 64 * 1024) {
+        static std::atomic<unsigned long long> configured{0};
+        if (lds > 64 * 1024 && fd_first_on_device(&configured))
             FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16<BM, BN, TRANS, CONV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured = true;
-        }
         hipLaunchKernelGGL((k_gemm_f16<BM, BN, TRANS, CONV>), grid, dim3(256), lds, st, g);
         FD_CHECK_LAUNCH("k_gemm_f16");
         return FD_OK;
@@ -1130,7 +1127,7 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
             choice[1] = 1;
             return FD_OK;
         }
-        fd_prof_begin(FD_FAMILY_GEMM, st, flops, flops_exec);
+        fd_prof_begin(FD_FAMILY_GEMM, st, flops, flops_exec, fd_tag(10u, g.M, g.N, g.K, vt160 ? 9 : 3));
         if (vt160)
             rc = g.ln_stats ? launch_mode<128, 160, true, false, 4, 2, 2, 7>(g, batch, st) : launch_mode<128, 160, true, false, 4, 2, 2, 0>(g, batch, st);
         else
@@ -1402,7 +1399,7 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
         choice[1] = best_split;
         return FD_OK;
     }
-    fd_prof_begin(FD_FAMILY_GEMM, st, flops, flops_exec);
+    fd_prof_begin(FD_FAMILY_GEMM, st, flops, flops_exec, fd_tag(11u, g.M * batch, g.N, g.K + g.K2, best_tile * 64 + best_split, (g.mode << 8) | (g.act << 4) | (g.res ? 2 : 0) | (g.ln_stats ? 1 : 0)));
     if (g.ln_stats && !(best_tile == 9 || best_tile == 10 || (best_tile >= 12 && best_tile <= 16) || best_tile == 20 || best_tile == 23 || best_tile >= 30)) {
         // small problems: the generic epilogue with the fold compiled in (64x64 for few rows)
         rc = best_tile == 4 ? launch_mode<64, 64, false, false, 2, 2, 2, 7>(g, batch, st)

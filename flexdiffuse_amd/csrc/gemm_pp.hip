@@ -98,7 +98,8 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
                                                      (unsigned)(n0 + wave * 64 + lane) * 4u, 0, 0, 0);
     }
     const int b_first = m0 / g.rows_per_batch;
-    const bool b2_staged = g.bias2 && g.bias_lds && (min(m0 + BM, g.M) - 1) / g.rows_per_batch == b_first;
+    // (LayerNorm fold: bias2 = the weights' column sums, ONE row for every sample -- ldb2 == 0 --, staged whatever the sample boundary)
+    const bool b2_staged = g.bias2 && g.bias_lds && (g.ln_stats != nullptr || (min(m0 + BM, g.M) - 1) / g.rows_per_batch == b_first);
     if (b2_staged || (EPI != 0 && EPI != 7)) {
         const __amdgpu_buffer_rsrc_t rsB2 = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(b2_staged ? (const void*)(g.bias2 + (size_t)b_first * g.ldb2) : (const void*)g.W), 0,
@@ -431,12 +432,10 @@ static int pp_launch_k2(GemmArgs& g, int batch, hipStream_t st) {
     const unsigned long long a_bytes = CONV ? 2ull * (((unsigned long long)(g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi - 1) * g.Cpix + g.Cin)
                                             : 2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K);
     const unsigned long long w_bytes = 2ull * ((unsigned long long)(g.N - 1) * g.ldw + g.K + g.K2);
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<unsigned long long> configured{0};   // per device: every ping-pong kernel needs ~150 KB of LDS
+    if (fd_first_on_device(&configured))
         FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_pp<WM_, WN_, MI, NI, CONV, EPI, HAS_K2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
     // split-K slices pinned to XCDs on a flat grid (see the kernel): -3.5..4 % on the 16x16-level convolutions (128-130 / 218-221 / 174-179 us
     // against 132-136 / 227-232 / 182-186, four interleaved samples each, profiles/r05_ab_pp.txt), neutral at split 2; FD_PP_SK_XCD=0: the 2-D grid (A/B)
     static const int sk_xcd = getenv("FD_PP_SK_XCD") ? atoi(getenv("FD_PP_SK_XCD")) : 1;

@@ -551,6 +551,7 @@ extern "C" int fd_guidance_tween(const float* base, const float* alt, const floa
     }
     int rc = check_shapes(B, N, L, D, "fd_guidance_tween");
     if (rc) return rc;
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(3u, __LINE__));
     FD_CHECK_ARG(base && alt && lin_w && ws && out && weights && idx && s && status && p,
                  FD_EINVAL, "fd_guidance_tween: null pointer");
     FD_CHECK_ARG(p->order >= 0 && p->order <= 2, FD_EINVAL, "fd_guidance_tween: order=%d",

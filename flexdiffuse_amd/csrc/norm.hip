@@ -359,17 +359,16 @@ static bool gn_try_slab(const void* x, void* y, const float* gamma, const float*
         if ((HW + pl - 1) / pl > NV) break;
         const size_t lds = ((size_t)pl * CB + (size_t)J * CB + GB * 2) * sizeof(float);
         if (lds > 160 * 1024) break;
-        static bool attr_set = false;   // per instantiation
-        if (!attr_set) {
+        static std::atomic<unsigned long long> attr_set{0};   // per instantiation and device
+        if (fd_first_on_device(&attr_set)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_slab<NT, NV>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 fd_set_error("fd_groupnorm_nhwc_f16: cannot raise the LDS limit");
                 *rc = FD_EHIP;
                 return true;
             }
-            attr_set = true;
         }
-        fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 4.0);
+        fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 4.0, -1.0, fd_tag(7u, B, HW, C, NT));
         // grid (B, G / GB), sample fastest (round 4): -10..-20 % on every slab shape against (G / GB, B)
         // (profiles/r04_session_ab.txt sec. 8: 16x1024x640 17.6 -> 14.0 us, 16x256x1280 10.2 -> 8.3 us)
         hipLaunchKernelGGL((k_gn_slab<NT, NV>), dim3(B, G / GB), dim3(NT), lds, st, (const half_t*)x,
@@ -482,7 +481,7 @@ extern "C" int fd_groupnorm_fold_linear_f16(const void* x, int ldx, float* ws, i
     const size_t lds2 = (size_t)GNF_ROWS * C * sizeof(half_t);
     FD_CHECK_ARG(lds2 <= 48 * 1024, FD_ESHAPE, "fd_groupnorm_fold_linear_f16: C=%d too wide for the fold kernel's weight tile", C);
     // priced as the statistics read only (2 B/element): the apply pass it replaces is gone
-    fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 2.0);
+    fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 2.0, -1.0, fd_tag(8u, B, HW, C, N));
     hipLaunchKernelGGL(k_gn_stats, dim3(nchunk, B), dim3(threads), lds1, st, (const half_t*)x, ws, HW, C, G, PL, ppc, ldx);
     hipLaunchKernelGGL(k_gn_fold_linear, dim3(fd_cdiv(N, GNF_ROWS), B), dim3(256), lds2, st, (const float*)ws, nchunk, HW, C, G, eps,
                        (const half_t*)wg, biasf, N, (half_t*)w_out, bias_out);
@@ -541,7 +540,7 @@ extern "C" int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const f
     // priced at SURVEY 8(d)'s ALGORITHMIC 4 B/element (fp16 read + write); the streaming pair really
     // moves 6 B/element (the statistics pass reads x once more, mostly from the Infinity Cache)
     const double bytes = (double)B * HW * C * 4.0;
-    fd_prof_begin(FD_FAMILY_GROUPNORM, st, bytes);
+    fd_prof_begin(FD_FAMILY_GROUPNORM, st, bytes, -1.0, fd_tag(9u, B, HW, C, ldx));
     hipLaunchKernelGGL(k_gn_stats, dim3(nchunk, B), dim3(threads), lds1, st, (const half_t*)x, ws,
                        HW, C, G, PL, ppc, ldx);
     const size_t lds2 = (size_t)2 * threads * sizeof(double) + (size_t)2 * G * sizeof(float);
@@ -632,6 +631,7 @@ extern "C" int fd_layernorm_f16(const void* x, void* y, const float* gamma, cons
                                 int rows, int C, int ldx, int ldy, float eps, int out_f32,
                                 void* stream) {
     FD_PLAN(fd_layernorm_f16(x, y, gamma, beta, rows, C, ldx, ldy, eps, out_f32, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(2u, __LINE__));
     FD_CHECK_ARG(x && y && gamma && beta && rows > 0 && C > 0, FD_EINVAL, "fd_layernorm_f16: args");
     FD_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && C <= 2048, FD_ESHAPE,
                  "fd_layernorm_f16: C=%d must be a multiple of 8 and <= 2048", C);
@@ -656,6 +656,7 @@ extern "C" int fd_layernorm_f16(const void* x, void* y, const float* gamma, cons
 
 extern "C" int fd_ln_row_stats_f16(const void* x, float* stats, int rows, int C, int ldx, float eps, void* stream) {
     FD_PLAN(fd_ln_row_stats_f16(x, stats, rows, C, ldx, eps, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(2u, __LINE__));
     FD_CHECK_ARG(x && stats && rows > 0 && C > 0, FD_EINVAL, "fd_ln_row_stats_f16: args");
     FD_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && C <= 2048, FD_ESHAPE,
                  "fd_ln_row_stats_f16: C=%d must be a multiple of 8 and <= 2048", C);
@@ -751,6 +752,7 @@ __global__ void k_ln_finalize(const float* __restrict__ parts, float* __restrict
 
 extern "C" int fd_ln_finalize_stats_f32(const float* partials, float* stats, int M, int N, int n_tiles, float eps, void* stream) {
     FD_PLAN(fd_ln_finalize_stats_f32(partials, stats, M, N, n_tiles, eps, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(2u, __LINE__));
     FD_CHECK_ARG(partials && stats && M > 0 && N > 0 && n_tiles >= 1 && n_tiles <= 64, FD_EINVAL, "fd_ln_finalize_stats_f32: args");
     const dim3 grid((M + 63) / 64), block(64);   // one wave per workgroup: 16384 rows spread over all 256 CUs
     const float inv_n = 1.0f / (float)N, e = eps > 0.f ? eps : 1e-5f;
@@ -768,6 +770,7 @@ extern "C" int fd_ln_finalize_stats_f32(const float* partials, float* stats, int
 
 extern "C" int fd_softmax_rows_f16(void* x, int rows, int N, int ld, float scale, void* stream) {
     FD_PLAN(fd_softmax_rows_f16(x, rows, N, ld, scale, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(2u, __LINE__));
     FD_CHECK_ARG(x && rows > 0 && N > 0, FD_EINVAL, "fd_softmax_rows_f16: args");
     FD_CHECK_ARG(N % 8 == 0 && ld % 8 == 0, FD_ESHAPE, "fd_softmax_rows_f16: N, ld %% 8");
     hipLaunchKernelGGL(k_softmax_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, (half_t*)x, N,

@@ -37,6 +37,7 @@ extern "C" int fd_device_info(int device, int* cu_count, int* clock_khz, int64_t
 // ---- kernel-family timing recorder -------------------------------------------------
 struct ProfRec {
     int family;
+    unsigned tag;
     double work, executed;
     hipEvent_t e0, e1;
 };
@@ -63,7 +64,7 @@ static hipEvent_t prof_event() {
     return e;
 }
 
-void fd_prof_begin(int family, hipStream_t s, double work, double executed) {
+void fd_prof_begin(int family, hipStream_t s, double work, double executed, unsigned tag) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     const int f = family & 7;
@@ -71,6 +72,7 @@ void fd_prof_begin(int family, hipStream_t s, double work, double executed) {
     if (!g_open[f]) return;
     ProfRec r;
     r.family = family;
+    r.tag = tag;
     r.work = work;
     r.executed = executed < 0 ? work : executed;
     r.e0 = prof_event();
@@ -162,6 +164,31 @@ extern "C" int fd_prof_collect2(int family, double* total_ms, double* total_work
     if (total_work) *total_work = work;
     if (total_executed) *total_executed = executed;
     if (launches) *launches = n;
+    return FD_OK;
+}
+
+// Every recorded bracket, one by one and in launch order (after synchronising its events), then forgets them all: what
+// bench.py's roofline leg aggregates robustly (median per (family, tag, work) group x its launch count) instead of a plain sum.
+// Host arrays of `cap` entries; *n = records written (records beyond `cap` are dropped).
+extern "C" int fd_prof_drain(int32_t* family, uint32_t* tag, float* ms, double* work, double* executed, int64_t cap, int64_t* n) {
+    FD_CHECK_ARG(family && tag && ms && work && executed && n && cap >= 0, FD_EINVAL, "fd_prof_drain: null pointer");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int64_t k = 0;
+    for (auto& r : g_prof) {
+        float t = 0.f;
+        if (k < cap && hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+            family[k] = r.family;
+            tag[k] = r.tag;
+            ms[k] = t;
+            work[k] = r.work;
+            executed[k] = r.executed;
+            ++k;
+        }
+        g_pool.push_back(r.e0);
+        g_pool.push_back(r.e1);
+    }
+    g_prof.clear();
+    *n = k;
     return FD_OK;
 }
 

@@ -139,6 +139,7 @@ extern "C" int fd_xattn_pack_kv_f16(const void* K, const void* Vt, void* kimg, v
                                     int64_t vt_sample_stride, void* stream) {
     FD_PLAN(fd_xattn_pack_kv_f16(K, Vt, kimg, vimg, samples, n_keys, heads, head_dim, ldk, ldvt, k_sample_stride,
                                  vt_sample_stride, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(4u, __LINE__));
     FD_CHECK_ARG(K && Vt && kimg && vimg && samples > 0, FD_EINVAL, "fd_xattn_pack_kv_f16: args");
     FD_CHECK_ARG(xa_supported(heads, head_dim) && n_keys >= 1 && n_keys <= 80, FD_ESHAPE,
                  "fd_xattn_pack_kv_f16: 8 heads x 40 or 8 x 80, at most 80 keys (got %d x %d, %d keys)", heads, head_dim, n_keys);
@@ -437,11 +438,9 @@ template <int D>
 static int xa_launch(const XattnArgs& g, int n_rep, unsigned a_bytes, unsigned w_bytes, unsigned o_bytes, hipStream_t st) {
     typedef XaCfg<D> cfg;
     constexpr size_t lds = 2 * (size_t)(cfg::BM + 320) * 128 + (2 * 320 + 2 * cfg::BM) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<unsigned long long> configured{0};
+    if (fd_first_on_device(&configured))
         FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xattn<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
     hipLaunchKernelGGL(k_xattn<D>, dim3(g.M / cfg::BM, n_rep, cfg::C / 320), dim3(1024), lds, st, g, a_bytes, w_bytes, o_bytes);
     return FD_OK;
 }
@@ -480,7 +479,7 @@ extern "C" int fd_xattn_q_f16(const fd_xattn_desc* d, void* stream) {
     // priced like the two launches it replaces: the q projection (2 M C C, once) and the attention proper
     // (4 heads Nq Nk d per replica)
     const double flops = 2.0 * d->M * (double)C * C + 4.0 * (double)d->n_rep * d->M * d->n_keys * C;
-    fd_prof_begin(FD_FAMILY_ATTENTION, st, flops);
+    fd_prof_begin(FD_FAMILY_ATTENTION, st, flops, -1.0, fd_tag(5u, d->M, d->n_rep, d->head_dim, d->n_keys));
     const int rc = d->head_dim == 40 ? xa_launch<40>(g, d->n_rep, (unsigned)a_bytes, (unsigned)w_bytes, (unsigned)o_bytes, st)
                                      : xa_launch<80>(g, d->n_rep, (unsigned)a_bytes, (unsigned)w_bytes, (unsigned)o_bytes, st);
     fd_prof_end(FD_FAMILY_ATTENTION, st);

@@ -38,6 +38,7 @@ _SIGNATURES = {
     'fd_prof_collect': (c_int, [c_int, P, P, P]),
     'fd_prof_collect2': (c_int, [c_int, P, P, P, P]),
     'fd_prof_calibrate': (c_int, [c_int, P, P]),
+    'fd_prof_drain': (c_int, [P, P, P, P, P, c_int64, P]),
     'fd_guidance_workspace_floats': (c_int64, [c_int, c_int, c_int]),
     'fd_guidance_map': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'fd_guidance_tween': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int,
@@ -81,7 +82,7 @@ _SIGNATURES = {
     'fd_cast_f16_to_f32': (c_int, [P, P, c_int64, P]),
 }
 
-ABI_VERSION = 10  # FD_ABI_VERSION in include/flexdiffuse_hip.h
+ABI_VERSION = 11  # FD_ABI_VERSION in include/flexdiffuse_hip.h
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -221,6 +222,18 @@ def prof_calibrate(pairs: int = 256) -> float:
     ms = c_double(0)
     call('fd_prof_calibrate', int(pairs), ctypes.byref(ms), stream())
     return ms.value
+
+
+def prof_drain(cap: int = 1 << 17):
+    '''Every recorded bracket in launch order as (family, tag, ms, work, executed) numpy arrays; forgets the records.'''
+    import numpy as np
+    fam, tag = np.zeros(cap, np.int32), np.zeros(cap, np.uint32)
+    ms, work, ex = np.zeros(cap, np.float32), np.zeros(cap, np.float64), np.zeros(cap, np.float64)
+    n = c_int64(0)
+    call('fd_prof_drain', fam.ctypes.data, tag.ctypes.data, ms.ctypes.data, work.ctypes.data, ex.ctypes.data, cap,
+         ctypes.byref(n))
+    k = n.value
+    return fam[:k], tag[:k], ms[:k], work[:k], ex[:k]
 
 
 def prof_collect(family: int):

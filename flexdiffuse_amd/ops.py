@@ -13,7 +13,7 @@ import torch
 from . import hip
 
 ACT_NONE, ACT_SILU, ACT_QUICK_GELU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3, 4
-FAMILY_GEMM, FAMILY_ATTENTION, FAMILY_GROUPNORM = 0, 1, 2
+FAMILY_GEMM, FAMILY_ATTENTION, FAMILY_GROUPNORM, FAMILY_OTHER = 0, 1, 2, 3
 
 
 class fd_gemm_desc(ctypes.Structure):
@@ -231,10 +231,11 @@ def conv2d_up_phases(x: Act, w: ConvW, out: Optional[torch.Tensor] = None) -> Ac
 def up_phases_supported(rows_low: int, cout: int, cin: int) -> bool:
     '''Shapes for which conv2d_up_phases is used instead of conv2d(..., up=True): full 256-row tiles, UNet / VAE widths,
     and enough low-resolution rows that four parity slices fill the chip without split-K (UNet widths: from 1024 rows -- the 8x8 -> 16x16
-    convolution of the bench forward: 68 us on the 3-stage 128x160 tile against 133 us for the fused-upsample form, tools/ab_up8.py; the VAE
-    widths have no 128-row tile with the parity row map: from 4096 rows).'''
+    convolution of the bench forward: 68 us on the 3-stage 128x160 tile against 133 us for the fused-upsample form, tools/ab_up8.py -- the
+    1024-row threshold holds for that measured class only, N >= 1280 and Cin >= 1280; narrower layers and the VAE widths, which have no
+    128-row tile with the parity row map: from 4096 rows).'''
     return (os.environ.get('FD_UP_PHASES', '1') != '0' and rows_low % 256 == 0
-            and rows_low >= int(os.environ.get('FD_UP_PHASES_MIN_ROWS', '1024' if cout % 160 == 0 else '4096'))
+            and rows_low >= int(os.environ.get('FD_UP_PHASES_MIN_ROWS', '1024' if cout % 160 == 0 and cout >= 1280 and cin >= 1280 else '4096'))
             and (cout % 160 == 0 or cout % 128 == 0) and cin % 64 == 0)
 
 

@@ -158,9 +158,11 @@ class FlexPipeline():
     def _unet_eps(self, latents: torch.Tensor, t: int, ctx: torch.Tensor, rep: int) -> torch.Tensor:
         '''UNet noise prediction (NHWC fp32) for the fused loop; graph-replayed when enabled.
         `latents` must be the loop's persistent buffer (updated in place by the DDIM kernel).'''
-        if self.use_plan and not self.use_graph:
+        # (per-launch event timing -- bench.py's roofline leg -- cannot see inside a graph: it replays the launch plan,
+        # the same kernels in the same order issued by one host call)
+        if (self.use_plan and not self.use_graph) or (self.use_graph and hip.prof_is_on()):
             return self._unet_eps_plan(latents, t, ctx, rep)
-        if not self.use_graph or hip.prof_is_on():   # event timing needs eager launches
+        if not self.use_graph:
             return self.unet.forward_nhwc(latents, t, ctx, rep=rep)
         self.unet.set_context(ctx)               # eager, in place: the graph reads these buffers
         # ctx_generation changes when the UNet had to reallocate its cached K / V^T (a call with
@@ -169,6 +171,7 @@ class FlexPipeline():
                getattr(self.unet, 'ctx_generation', 0))
         entry = self._graphs.get(key)
         if entry is None:
+            self._graphs = {}                    # drop the previous graph (its private pool holds GBs) before capturing another
             t_static = torch.zeros((1,), dtype=torch.float32, device=latents.device)
             # the first call runs eagerly (lazy one-time setup inside the kernels' launchers),
             # the second is captured
@@ -185,7 +188,11 @@ class FlexPipeline():
                 self.graph_fallback = f'HIP-graph capture failed ({type(ex).__name__}: {str(ex)[:200]}); running on the launch plan'
                 warnings.warn(self.graph_fallback, RuntimeWarning)
                 self.use_graph, self.use_plan, self._graphs = False, True, {}
-                torch.cuda.synchronize()
+                try:                     # a stream left in (or invalidated by) the failed capture must not fail the request either
+                    if not torch.cuda.is_current_stream_capturing():
+                        torch.cuda.synchronize()
+                except Exception:        # noqa: BLE001
+                    pass
                 return self._unet_eps_plan(latents, t, ctx, rep)
             entry = (graph, t_static, eps, ctx)
             self._graphs = {key: entry}          # keep one graph (its pool holds GBs)

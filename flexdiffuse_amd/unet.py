@@ -464,7 +464,7 @@ class UNet2DConditionModel():
                     h = self._res(r, h, temb, out=dst)
             if blk['up'] is not None:
                 dst = left(h.B * h.HW * 4, blk['up'].cout)
-                if blk.get('up_ph') is not None and ops.up_phases_supported(h.B * h.HW, blk['up'].cout, blk['up'].cin):
+                if blk.get('up_ph') is not None and h.t.is_contiguous() and ops.up_phases_supported(h.B * h.HW, blk['up'].cout, blk['up'].cin):
                     h = ops.conv2d_up_phases(h, blk['up_ph'], out=dst)
                 else:
                     h = ops.conv2d(h, blk['up'], up=True, out=dst)

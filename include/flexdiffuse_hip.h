@@ -32,7 +32,7 @@ extern "C" {
 #define FD_ESHAPE (-2) /* unsupported shape / alignment */
 #define FD_EHIP (-3)   /* HIP runtime error */
 
-#define FD_ABI_VERSION 10
+#define FD_ABI_VERSION 11
 
 int fd_abi_version(void);
 const char* fd_last_error(void);
@@ -45,6 +45,7 @@ int fd_device_info(int device, int* cu_count, int* clock_khz, int64_t* hbm_bytes
 #define FD_FAMILY_GEMM 0      /* implicit-GEMM conv / GEMM MFMA kernel */
 #define FD_FAMILY_ATTENTION 1 /* flash attention MFMA kernel */
 #define FD_FAMILY_GROUPNORM 2 /* GroupNorm(+SiLU) statistics + apply */
+#define FD_FAMILY_OTHER 3     /* (ABI 11) every other launch of the library: layout / elementwise / LayerNorm statistics / guidance */
 int fd_prof_enable(int on);
 /* Record events around every `stride`-th launch of each family only (default 1 = all): a pair of
  * event records costs ~6.6 us of stream time, which at one pair per launch is ~10 % of the pass
@@ -58,6 +59,11 @@ int fd_prof_collect(int family, double* total_ms, double* total_work, int64_t* l
  * where a launch implements an op with fewer MACs than its definition (parity-decomposed upsample convolution: 4/9).
  * The hardware roofline is `executed` / time; `work` / time is the algorithmic-equivalent rate. */
 int fd_prof_collect2(int family, double* total_ms, double* total_work, double* total_executed, int64_t* launches);
+/* (ABI 11) Every recorded bracket one by one, in launch order: family, tag (an identity of the launch's shape and kernel choice; 0 =
+ * none), elapsed ms, declared and executed work; then forgets all records.  Host arrays of `cap` entries, *n = entries written.
+ * bench.py's roofline leg (the measurement of the `unet(...)` call of reference pipeline/guide.py:56-58) takes the MEDIAN per
+ * (family, tag, work) group x the group's launch count, so one host stall inside one bracket cannot move a family's total. */
+int fd_prof_drain(int32_t* family, uint32_t* tag, float* ms, double* work, double* executed, int64_t cap, int64_t* n);
 /* Mean elapsed ms of an EMPTY event bracket (`pairs` back-to-back record pairs on `stream`);
  * subtract it per sampled launch to turn bracket time into kernel time. Host pointer. */
 int fd_prof_calibrate(int pairs, double* ms_per_empty_pair, void* stream);

@@ -18,6 +18,15 @@ def check_bench_line(d: dict, full: bool) -> None:
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 2516.6
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['executed_frac'] <= r['frac'] < 1
     assert r['families_fit_in_step'] and r['families_ms_per_pass'] <= d['ms_per_step']
+    if 'time_budget_ms' in r:            # (lines from round 6 on) where the step's time goes, summing to ms_per_step
+        b = r['time_budget_ms']
+        assert set(b) == {'gemm', 'attention', 'groupnorm', 'other_kernels', 'gaps_and_host'}
+        assert abs(sum(b.values()) - d['ms_per_step']) <= 0.03 * d['ms_per_step']
+        assert all(v >= 0 for v in b.values()), b
+        assert r['roofline_valid'] is True and r['roofline_retries'] in (0, 1)
+        assert abs(b['gemm'] - r['kernel_ms_per_pass']) < 1e-6 and abs(b['groupnorm'] - r['groupnorm_ms_per_pass']) < 1e-6
+        # the median-based family time may not be far from the plain sum of the same brackets unless a bracket was hit by a stall
+        assert r['kernel_ms_per_pass'] <= 1.25 * max(r['kernel_ms_per_pass_plain_sum'], 1e-9)
     if 'traffic_stale' in r:             # (lines from round 5 on) the PMC record is tied to the GEMM sources it was measured on
         assert isinstance(r['traffic_stale'], bool)
         assert ('stale' in r['traffic_of']) == r['traffic_stale']

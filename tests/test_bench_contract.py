@@ -40,6 +40,41 @@ def test_traffic_record_is_tied_to_the_sources():
     assert stale == (not matching)
 
 
+def test_roofline_aggregation_survives_a_host_stall():
+    '''bench.aggregate_brackets: median per launch shape x count.  Round 5's driver line carried a 39 ms host stall inside ONE
+    GroupNorm bracket (x the sampling stride = 273 ms of "GroupNorm"); here the same stall moves nothing, and time_budget sums
+    to the step.'''
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    argv, sys.argv = sys.argv, ['bench.py']
+    try:
+        import bench
+    finally:
+        sys.argv = argv
+    rng = np.random.default_rng(0)
+    fam, tag, ms, work = [], [], [], []
+    shapes = [(0, 11, 0.100, 1e11), (0, 12, 0.030, 2e10), (1, 21, 0.380, 3e11), (2, 31, 0.029, 4e8), (2, 32, 0.008, 1e7), (3, 41, 0.004, 0.0)]
+    for f, t, dur, w in shapes:
+        for _ in range(200):
+            fam.append(f), tag.append(t), ms.append(dur * (1 + 0.01 * rng.standard_normal()) + 0.005), work.append(w)
+    clean = bench.aggregate_brackets(fam, tag, ms, work, work, 0.005)
+    i = fam.index(2)
+    ms[i] += 39.0                                    # the stall
+    hit = bench.aggregate_brackets(fam, tag, ms, work, work, 0.005)
+    assert abs(hit['groupnorm']['ms'] - clean['groupnorm']['ms']) < 0.01 * clean['groupnorm']['ms']
+    assert hit['groupnorm']['raw_ms'] > clean['groupnorm']['raw_ms'] + 38.0
+    assert hit['groupnorm']['worst_bracket_over_median'] > 100 and clean['groupnorm']['worst_bracket_over_median'] < 1.2
+    assert abs(clean['gemm']['ms'] - 200 * (0.100 + 0.030)) < 0.3 and clean['gemm']['groups'] == 2 and clean['gemm']['launches'] == 400
+    assert abs(clean['gemm']['work'] - 200 * 1.2e11) < 1.0
+    step = 140.0
+    budget, ok = bench.time_budget(hit, step)
+    assert ok and abs(sum(budget.values()) - step) < 1e-9 and budget['gaps_and_host'] > 0
+    assert not bench.time_budget(hit, 50.0)[1]
+    # with a sampling stride every sampled bracket stands for `stride` launches
+    s7 = bench.aggregate_brackets(fam[::7], tag[::7], ms[::7], work[::7], work[::7], 0.005, stride=7)
+    assert abs(s7['attention']['ms'] - clean['attention']['ms']) < 0.05 * clean['attention']['ms']
+
+
 def test_bench_defaults_finish_in_minutes_and_help_parses():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, timeout=120)
     assert r.returncode == 0

@@ -173,6 +173,33 @@ def test_scheduler_comes_from_the_checkpoint_directory(tmp_path):
     cfg.write_text(json.dumps({'_class_name': 'EulerDiscreteScheduler'}))
     with pytest.raises(NotImplementedError):
         build.load_scheduler(str(tmp_path))
+    # PNDM / LMS have no v-prediction arithmetic -- a v-prediction checkpoint (sd21 / mini2 presets, or the file's own
+    # prediction_type) with such a scheduler file is refused, never stepped as epsilon; DDIM carries the type through
+    sd_pndm = {'_class_name': 'PNDMScheduler', 'beta_end': 0.012, 'beta_schedule': 'scaled_linear', 'beta_start': 0.00085,
+               'num_train_timesteps': 1000, 'skip_prk_steps': True}
+    cfg.write_text(json.dumps(sd_pndm))
+    with pytest.raises(NotImplementedError, match='v_prediction'):
+        build.load_scheduler(str(tmp_path), build.configs('mini2')[0].prediction_type)
+    cfg.write_text(json.dumps(dict(sd_pndm, prediction_type='v_prediction')))
+    with pytest.raises(NotImplementedError, match='v_prediction'):
+        build.load_scheduler(str(tmp_path))
+    cfg.write_text(json.dumps(dict(sd_pndm, _class_name='LMSDiscreteScheduler')))
+    with pytest.raises(NotImplementedError, match='v_prediction'):
+        build.load_scheduler(str(tmp_path), 'v_prediction')
+    cfg.write_text(json.dumps({'_class_name': 'DDIMScheduler', 'beta_start': 0.00085, 'beta_end': 0.012, 'beta_schedule': 'scaled_linear',
+                               'num_train_timesteps': 1000, 'clip_sample': False, 'set_alpha_to_one': False}))
+    assert build.load_scheduler(str(tmp_path), 'v_prediction').config['prediction_type'] == 'v_prediction'
+    # keys the file leaves out take DIFFUSERS' defaults, not this package's SD presets: a PNDM file without skip_prk_steps means the
+    # Runge-Kutta warm-up (not provided: refused), one without betas means linear 1e-4 .. 0.02 (not provided by PNDM / LMS: refused)
+    cfg.write_text(json.dumps({k: v for k, v in sd_pndm.items() if k != 'skip_prk_steps'}))
+    with pytest.raises(NotImplementedError):
+        build.load_scheduler(str(tmp_path))
+    cfg.write_text(json.dumps({'_class_name': 'LMSDiscreteScheduler'}))
+    with pytest.raises(NotImplementedError):
+        build.load_scheduler(str(tmp_path))
+    cfg.write_text(json.dumps({'_class_name': 'DDIMScheduler', 'clip_sample': False}))
+    s = build.load_scheduler(str(tmp_path))
+    assert s.config['beta_schedule'] == 'linear' and s.config['beta_end'] == 0.02 and s.config['set_alpha_to_one'] is True
 
 
 def test_devmon_and_bench_clock_fields_without_a_gpu():
