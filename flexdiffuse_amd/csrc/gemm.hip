@@ -24,6 +24,7 @@
 // interleaved weight rows), residual add, fp16 or fp32 store, or a transposed store
 // ([b][n][m]) used to emit V^T for the attention kernel.
 #include "gemm_epilogue.h"
+#include "gn_slab.h"
 
 typedef const __attribute__((address_space(1))) half_t* gptr_h;   // force global_load (not flat)
 typedef const __attribute__((address_space(1))) u32x4* gptr_u4;
@@ -814,6 +815,121 @@ __global__ __launch_bounds__(256) void k_splitk_finish(GemmArgs g) {
     }
 }
 
+
+// Split-K finish FUSED with the GroupNorm(+SiLU) that consumes the output (fd_gemm_desc.gn_out): a workgroup owns one sample x
+// gn_gb groups, sums the fp32 partial slabs of its [HW][gn_gb * cpg] slab in the finish kernel's fixed order, applies bias +
+// per-sample bias (+ residual), rounds to fp16 -- the convolution's output, stored to C unless gn_skip_c -- and normalises those
+// registers with the slab GroupNorm body (gn_slab.h): same bits as k_splitk_finish followed by k_gn_slab<256, 16>, one launch
+// and one fp16 round trip through HBM less.  All of a vector's slab loads are issued together (S is a template parameter).
+template <int S>
+__global__ __launch_bounds__(256) void k_splitk_finish_gn(GemmArgs g) {
+    extern __shared__ float gn_sm[];
+    constexpr int NT = 256, NV = 16;
+    const int HW = g.rows_per_batch, C = g.N, cpg = C / g.gn_groups, GB = g.gn_gb, CB = cpg * GB, c8 = CB >> 3;
+    const int b = blockIdx.x, ch0 = blockIdx.y * CB, tid = threadIdx.x;
+    const int cc = tid % c8;
+    const int n = ch0 + cc * 8;
+    float bs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bs[k] = 0.f;
+    if (g.bias) {
+        const float4 lo = *reinterpret_cast<const float4*>(g.bias + n), hi = *reinterpret_cast<const float4*>(g.bias + n + 4);
+        bs[0] = lo.x; bs[1] = lo.y; bs[2] = lo.z; bs[3] = lo.w; bs[4] = hi.x; bs[5] = hi.y; bs[6] = hi.z; bs[7] = hi.w;
+    }
+    if (g.bias2) {   // bias + per-sample bias first, then one fma (as every epilogue of the family)
+        const float* b2 = g.bias2 + (size_t)b * g.ldb2 + n;
+        const float4 lo = *reinterpret_cast<const float4*>(b2), hi = *reinterpret_cast<const float4*>(b2 + 4);
+        bs[0] += lo.x; bs[1] += lo.y; bs[2] += lo.z; bs[3] += lo.w; bs[4] += hi.x; bs[5] += hi.y; bs[6] += hi.z; bs[7] += hi.w;
+    }
+    const size_t slab = (size_t)g.M * g.N;
+    const size_t row0 = (size_t)b * HW;
+    const float* __restrict__ src0 = g.ws + row0 * g.N + n;
+    const int PL = NT / c8, pl = tid / c8;
+    const int nv = (HW + PL - 1) / PL;          // vectors a thread of this launch really holds (uniform)
+    const bool active = pl < PL;
+    // CH vectors at a time with ALL their 2 S CH slab loads issued before the first use (addresses clamped instead of
+    // predicated: a branch per vector made every vector its own load -> wait -> add round trip, 6 of them at the 16x16 level)
+    constexpr int CH = S >= 16 ? 1 : (S >= 8 ? 2 : (S >= 4 ? 4 : 8));
+    static_assert(NV % CH == 0, "whole chunks");
+    auto fill = [&](uint4(&v)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i0 = 0; i0 < NV; i0 += CH) {
+            if (i0 < nv) {
+                float4 lo[CH][S], hi[CH][S];
+                half8 rr[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int p = min(pl + PL * (i0 + j), HW - 1);
+                    const float* src = src0 + (size_t)p * g.N;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        lo[j][s] = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
+                        hi[j][s] = *reinterpret_cast<const float4*>(src + (size_t)s * slab + 4);
+                    }
+                }
+                if (g.res) {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+                        rr[j] = *reinterpret_cast<const half8*>(g.res + (row0 + min(pl + PL * (i0 + j), HW - 1)) * g.ldr + n);
+                }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    float a[8] = {lo[j][0].x, lo[j][0].y, lo[j][0].z, lo[j][0].w, hi[j][0].x, hi[j][0].y, hi[j][0].z, hi[j][0].w};
+#pragma unroll
+                    for (int s = 1; s < S; ++s) {   // fixed order
+                        a[0] += lo[j][s].x; a[1] += lo[j][s].y; a[2] += lo[j][s].z; a[3] += lo[j][s].w;
+                        a[4] += hi[j][s].x; a[5] += hi[j][s].y; a[6] += hi[j][s].z; a[7] += hi[j][s].w;
+                    }
+                    half8 o;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float val = fmaf(a[k], g.alpha, bs[k]);
+                        if (g.res) val += (float)rr[j][k];
+                        o[k] = (half_t)val;
+                    }
+                    const int p = pl + PL * (i0 + j);
+                    const bool valid = active && p < HW;
+                    const uint4 packed = *reinterpret_cast<uint4*>(&o);
+                    v[i0 + j] = valid ? packed : make_uint4(0u, 0u, 0u, 0u);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) v[i0 + j] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        // the convolution's own output (unless gn_skip_c), in a loop of its own: stores inside the chunk loop above made hipcc keep
+        // the whole v[] array in scratch memory
+        if (!g.gn_skip_c && active) {
+            half_t* __restrict__ cb = reinterpret_cast<half_t*>(g.C) + row0 * g.ldc + n;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int p = pl + PL * i;
+                if (p < HW) *reinterpret_cast<uint4*>(cb + (size_t)p * g.ldc) = v[i];
+            }
+        }
+    };
+    gn_slab_body<NT, NV>(fill, g.gn_out + row0 * C + ch0, g.gn_gamma + ch0, g.gn_beta + ch0, HW, C, cpg, GB, g.gn_eps, g.gn_silu, gn_sm);
+}
+
+template <int S>
+static int launch_finish_gn(const GemmArgs& g, hipStream_t st) {
+    size_t lds = 0;
+    const int GB = gn_slab_pick<256, 16>(g.rows_per_batch, g.N, g.gn_groups, &lds);
+    static std::atomic<unsigned long long> configured{0};
+    if (lds > 64 * 1024 && fd_first_on_device(&configured))
+        FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_splitk_finish_gn<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_splitk_finish_gn<S>, dim3(g.M / g.rows_per_batch, g.gn_groups / GB), dim3(256), lds, st, g);
+    FD_CHECK_LAUNCH("k_splitk_finish_gn");
+    return FD_OK;
+}
+
+extern "C" int fd_gemm_can_fuse_groupnorm(int M, int N, int rows_per_sample, int groups, int split_k) {
+    if (M <= 0 || N <= 0 || rows_per_sample <= 0 || groups <= 0 || M % rows_per_sample != 0 || N % 8 != 0 || N % groups != 0) return 0;
+    if (!(split_k == 2 || split_k == 4 || split_k == 8 || split_k == 16)) return 0;
+    size_t lds = 0;
+    return gn_slab_pick<256, 16>(rows_per_sample, N, groups, &lds) > 0 ? 1 : 0;
+}
+
 // --------------------------------------------------------------------------------------
 static bool g_use_dma = getenv("FD_GEMM_NO_DMA") == nullptr;
 static const int g_vae15 = 1;   // 256x256 tiles on the VAE widths (A/B closed in round 1: +19..33 %)
@@ -1016,7 +1132,7 @@ extern "C" int fd_gemm_plan(const fd_gemm_desc* d, int* tile, int* split_k) {
 }
 
 static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
-    FD_CHECK_ARG(d && d->A && d->W && d->C, FD_EINVAL, "fd_gemm_f16: null pointer");
+    FD_CHECK_ARG(d && d->A && d->W && (d->C || (d->gn_out && d->gn_skip_c)), FD_EINVAL, "fd_gemm_f16: null pointer");
     FD_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, FD_EINVAL, "fd_gemm_f16: M/N/K must be > 0");
     FD_CHECK_ARG(d->K % 8 == 0 && d->ldw % 8 == 0, FD_ESHAPE,
                  "fd_gemm_f16: K=%d and ldw=%d must be multiples of 8", d->K, d->ldw);
@@ -1031,7 +1147,7 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
     g.bias2 = d->bias2;
     g.res = (const half_t*)d->residual;
     g.M = d->M; g.N = d->N; g.K = d->K;
-    g.lda = d->lda; g.ldw = d->ldw; g.ldc = d->ldc; g.ldr = d->ldr;
+    g.lda = d->lda; g.ldw = d->ldw; g.ldc = d->C ? d->ldc : d->N; g.ldr = d->ldr;
     g.ldb2 = d->ld_bias2 > 0 ? d->ld_bias2 : d->N;
     g.strideA = d->batch_stride_a; g.strideW = d->batch_stride_w;
     g.strideC = d->batch_stride_c; g.strideRes = d->batch_stride_res;
@@ -1105,6 +1221,22 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
         g.ln_stats = d->ln_stats;
         g.bias2 = d->ln_colsum;   // one row for every sample: row stride 0
         g.ldb2 = 0;
+    }
+    if (d->gn_out) {
+        // GroupNorm(+SiLU) of the output inside the split-K finish (k_splitk_finish_gn)
+        FD_CHECK_ARG(d->gn_gamma && d->gn_beta && d->gn_groups > 0 && d->N % d->gn_groups == 0 && d->N % 8 == 0 && d->M % g.rows_per_batch == 0,
+                     FD_EINVAL, "fd_gemm_f16: gn_out needs gn_gamma, gn_beta, gn_groups | N, N %% 8 == 0 and whole samples (rows_per_sample | M)");
+        FD_CHECK_ARG(!d->out_f32 && !d->trans_out && d->act == FD_ACT_NONE && batch == 1 && !d->ln_stats && !d->ln_stats_out &&
+                         (uintptr_t)d->gn_out % 16 == 0 && (g.ldc & 7) == 0 && (!g.res || (g.ldr & 7) == 0) && (g.ldb2 & 3) == 0 &&
+                         (!g.bias2 || (uintptr_t)g.bias2 % 16 == 0) && (!g.res || (uintptr_t)g.res % 16 == 0),
+                     FD_ESHAPE, "fd_gemm_f16: gn_out needs a plain fp16 output (act NONE, batch 1, no LayerNorm fold), ldc / ldr %% 8 == 0, 16-byte aligned gn_out / bias2 / residual");
+        size_t gn_lds = 0;
+        g.gn_gb = gn_slab_pick<256, 16>(g.rows_per_batch, d->N, d->gn_groups, &gn_lds);
+        FD_CHECK_ARG(g.gn_gb > 0, FD_ESHAPE, "fd_gemm_f16: gn_out: a [%d][%d / %d groups] slab does not fit the finish kernel (fd_gemm_can_fuse_groupnorm)",
+                     g.rows_per_batch, d->N, d->gn_groups);
+        g.gn_out = (half_t*)d->gn_out; g.gn_gamma = d->gn_gamma; g.gn_beta = d->gn_beta;
+        g.gn_groups = d->gn_groups; g.gn_silu = d->gn_silu; g.gn_skip_c = d->gn_skip_c;
+        g.gn_eps = d->gn_eps > 0.f ? d->gn_eps : 1e-5f;
     }
     hipStream_t st = (hipStream_t)stream;
     // priced at the ALGORITHMIC work of the op it implements: the phase-decomposed upsample convolution (batch 4, K = 4 Cin)
@@ -1399,6 +1531,9 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
         choice[1] = best_split;
         return FD_OK;
     }
+    if (g.gn_out)
+        FD_CHECK_ARG(best_split == 2 || best_split == 4 || best_split == 8 || best_split == 16, FD_ESHAPE,
+                     "fd_gemm_f16: gn_out is honoured by split-K launches only (this one: tile %d, split_k %d); ask fd_gemm_plan first", best_tile, best_split);
     fd_prof_begin(FD_FAMILY_GEMM, st, flops, flops_exec, fd_tag(11u, g.M * batch, g.N, g.K + g.K2, best_tile * 64 + best_split, (g.mode << 8) | (g.act << 4) | (g.res ? 2 : 0) | (g.ln_stats ? 1 : 0)));
     if (g.ln_stats && !(best_tile == 9 || best_tile == 10 || (best_tile >= 12 && best_tile <= 16) || best_tile == 20 || best_tile == 23 || best_tile >= 30)) {
         // small problems: the generic epilogue with the fold compiled in (64x64 for few rows)
@@ -1433,7 +1568,14 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
 #ifdef FD_SPLITK_NO_FINISH   // timing-only variant (tools/seam_probe.py): the chain without the finish launch
     if (false) {
 #else
-    if (rc == FD_OK && g.split_k > 1) {
+    if (rc == FD_OK && g.split_k > 1 && g.gn_out) {
+        switch (g.split_k) {
+            case 2: rc = launch_finish_gn<2>(g, st); break;
+            case 4: rc = launch_finish_gn<4>(g, st); break;
+            case 8: rc = launch_finish_gn<8>(g, st); break;
+            default: rc = launch_finish_gn<16>(g, st); break;
+        }
+    } else if (rc == FD_OK && g.split_k > 1) {
 #endif
         const size_t total = (size_t)g.M * (g.N / 4);
         const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

@@ -47,6 +47,12 @@ struct GemmArgs {
     int stats_rows;         // ln_stats_out: rows of the whole launch (batch x M): slab stride of the partial sums
     int sk_flat;   // split-K on a flat 1-D grid: slice = blockIdx.x % split_k, tile = blockIdx.x / split_k (see k_gemm_f16_dma)
     float* ws;     // [split_k][M][N] fp32
+    // GroupNorm(+SiLU) of the output fused into the split-K finish (k_splitk_finish_gn, fd_gemm_desc.gn_out)
+    half_t* gn_out;
+    const float* gn_gamma;
+    const float* gn_beta;
+    int gn_groups, gn_silu, gn_gb, gn_skip_c;   // gn_gb: groups per workgroup (gn_slab_pick)
+    float gn_eps;
 };
 
 // Exact-form GELU  x * Phi(x),  Phi(x) = 0.5 * (1 + erf(x / sqrt 2)),  with erf from Abramowitz &

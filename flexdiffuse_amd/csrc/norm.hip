@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gn_slab.h"
 
 #define GN_MAX_CHUNKS 256
 
@@ -108,11 +109,6 @@ __global__ void k_gn_stats(const half_t* __restrict__ x, float* __restrict__ par
             dst[1] = bq;
         }
     }
-}
-
-__device__ __forceinline__ float gn_act(float f, int silu) {
-    // SiLU with the hardware reciprocal (1 ulp; the result is rounded to fp16 anyway)
-    return silu ? f * __builtin_amdgcn_rcpf(1.0f + __expf(-f)) : f;
 }
 
 // y = x*scale + shift (+SiLU).  Prologue: all threads combine the per-chunk partials (fp64,
@@ -225,10 +221,9 @@ __global__ void k_gn_apply(const half_t* __restrict__ x, half_t* __restrict__ y,
 }
 
 // Slab GroupNorm(+SiLU) in ONE launch and ONE read of x: a workgroup of NT threads owns one
-// sample x GB consecutive groups; its [HW][GB*cpg] slab is read once into registers (thread
-// t keeps the fixed 8-channel chunk t % c8 of pixels t / c8, +PL, ... -- at most NV 16-byte
-// vectors), statistics are reduced through LDS in a fixed order, then the same registers are
-// normalised and stored.  4 B of HBM traffic per element instead of 6, no partials, no second
+// sample x GB consecutive groups; its [HW][GB*cpg] slab is read once into registers, statistics are reduced through
+// LDS in a fixed order, then the same registers are normalised and stored (gn_slab.h: the body is shared with the
+// split-K finish of gemm.hip).  4 B of HBM traffic per element instead of 6, no partials, no second
 // launch.  <256,16> serves the 16x16 / 8x8 UNet levels, <1024,22> slabs up to ~400 KB (the
 // 64x64 and 32x32 levels whenever (HW * cpg*GB/8) / 1024 <= 22).
 template <int NT, int NV>
@@ -239,146 +234,50 @@ __global__ __launch_bounds__(NT) void k_gn_slab(const half_t* __restrict__ x, ha
     extern __shared__ float sm[];
     const int cpg = C / G, CB = cpg * GB, c8 = CB >> 3;
     const int PL = NT / c8;
-    const int J = NT / (CB >> 1);     // second-level partial rows
-    float* part = sm;                 // [PL][CB/2][2]  (sum, sumsq) per channel pair
-    float* part2 = sm + PL * CB;      // [J][CB/2][2]
-    float* gst = part2 + J * CB;      // [GB][2] mean, rstd
     // grid (B, G / GB): consecutive workgroup ids go round-robin over the 8 XCDs, so with the SAMPLE as the fast index all group
     // blocks of one sample -- whose 40..160-byte row segments share 128-byte lines -- run on one XCD and meet in its L2
     const int b = blockIdx.x, ch0 = blockIdx.y * CB, tid = threadIdx.x;
     const int cc = tid % c8, pl = tid / c8;
-    const bool active = pl < PL;
     // uniform 64-bit base + 32-bit per-lane offsets (keeps the address math out of VGPR pairs)
     const half_t* xb = x + (size_t)b * HW * ldx + ch0;
-    half_t* yb = y + (size_t)b * HW * C + ch0;
-    const unsigned off0 = (unsigned)(pl * C + cc * 8), ostep = (unsigned)(PL * C);
     const unsigned xoff0 = (unsigned)(pl * ldx + cc * 8), xstep = (unsigned)(PL * ldx);
-    // statistics per channel PAIR with v_dot2_f32_f16 (packed fp16 in, fp32 accumulate): cpg is
-    // even (checked by the launcher), so a pair never straddles two groups
-    uint4 v[NV];
-    float s[4], q[4];
+    const bool active = pl < PL;
+    gn_slab_body<NT, NV>(
+        [&](uint4(&v)[NV]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s[k] = q[k] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int p = pl + PL * i;
-        v[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (active && p < HW) v[i] = *reinterpret_cast<const uint4*>(xb + (xoff0 + xstep * i));
-    }
-    const half2v one2 = {(half_t)1.0f, (half_t)1.0f};
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const unsigned w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};   // zeros beyond HW add nothing
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const half2v h = __builtin_bit_cast(half2v, w[k]);
-            s[k] = __builtin_amdgcn_fdot2(h, one2, s[k], false);
-            q[k] = __builtin_amdgcn_fdot2(h, h, q[k], false);
-        }
-    }
-    const int CP = CB >> 1;           // channel pairs
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            part[(pl * CP + cc * 4 + k) * 2 + 0] = s[k];
-            part[(pl * CP + cc * 4 + k) * 2 + 1] = q[k];
-        }
-    }
-    __syncthreads();
-    {   // level 1: thread (j, c) sums pixel lanes j, j+J, ... of channel pair c
-        const int c = tid % CP, j = tid / CP;
-        if (j < J) {
-            float a = 0.f, bq = 0.f;
-            for (int l = j; l < PL; l += J) {
-                a += part[(l * CP + c) * 2 + 0];
-                bq += part[(l * CP + c) * 2 + 1];
+            for (int i = 0; i < NV; ++i) {
+                const int p = pl + PL * i;
+                v[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (active && p < HW) v[i] = *reinterpret_cast<const uint4*>(xb + (xoff0 + xstep * i));
             }
-            part2[(j * CP + c) * 2 + 0] = a;
-            part2[(j * CP + c) * 2 + 1] = bq;
-        }
-    }
-    __syncthreads();
-    {   // level 2: one wavefront per group sums its J x cpg values (fp64, fixed order)
-        const int lane = tid & 63, wave = tid >> 6;
-        for (int g = wave; g < GB; g += NT / 64) {
-            double a = 0.0, bq = 0.0;
-            const int ppg = cpg >> 1;   // pairs per group
-            for (int i = lane; i < J * ppg; i += 64) {
-                const int j = i / ppg, c = g * ppg + (i - j * ppg);
-                a += (double)part2[(j * CP + c) * 2 + 0];
-                bq += (double)part2[(j * CP + c) * 2 + 1];
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                a += __shfl_xor(a, o, 64);
-                bq += __shfl_xor(bq, o, 64);
-            }
-            if (lane == 0) {
-                const double n = (double)HW * cpg;
-                const double mean = a / n;
-                double var = bq / n - mean * mean;
-                if (var < 0.0) var = 0.0;
-                gst[g * 2 + 0] = (float)mean;
-                gst[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-            }
-        }
-    }
-    __syncthreads();
-    if (!active) return;
-    float sc[8], sh[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int c = cc * 8 + k, g = c / cpg;
-        const float a = gst[g * 2 + 1] * gamma[ch0 + c];
-        sc[k] = a;
-        sh[k] = beta[ch0 + c] - gst[g * 2 + 0] * a;
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int p = pl + PL * i;
-        if (p >= HW) break;
-        const half8 h = *reinterpret_cast<const half8*>(&v[i]);
-        half8 o;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = (half_t)gn_act(fmaf((float)h[k], sc[k], sh[k]), silu);
-        *reinterpret_cast<uint4*>(yb + (off0 + ostep * i)) = *reinterpret_cast<uint4*>(&o);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+        },
+        y + (size_t)b * HW * C + ch0, gamma + ch0, beta + ch0, HW, C, cpg, GB, eps, silu, sm);
 }
 
 template <int NT, int NV>
 static bool gn_try_slab(const void* x, void* y, const float* gamma, const float* beta, int B,
                         int HW, int C, int G, float eps, int silu, hipStream_t st, int* rc, int ldx) {
-    const int cpg = C / G;
-    if (cpg & 1) return false;
-    for (int GB = 1; GB <= 8 && GB <= G; GB *= 2) {
-        if (G % GB || (cpg * GB) % 8) continue;
-        const int CB = cpg * GB, cb8 = CB / 8;
-        if (cb8 > NT || CB / 2 > NT) break;
-        const int pl = NT / cb8, J = NT / (CB / 2);
-        if ((HW + pl - 1) / pl > NV) break;
-        const size_t lds = ((size_t)pl * CB + (size_t)J * CB + GB * 2) * sizeof(float);
-        if (lds > 160 * 1024) break;
-        static std::atomic<unsigned long long> attr_set{0};   // per instantiation and device
-        if (fd_first_on_device(&attr_set)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_slab<NT, NV>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                fd_set_error("fd_groupnorm_nhwc_f16: cannot raise the LDS limit");
-                *rc = FD_EHIP;
-                return true;
-            }
+    size_t lds = 0;
+    const int GB = gn_slab_pick<NT, NV>(HW, C, G, &lds);
+    if (!GB) return false;
+    static std::atomic<unsigned long long> attr_set{0};   // per instantiation and device
+    if (fd_first_on_device(&attr_set)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_slab<NT, NV>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            fd_set_error("fd_groupnorm_nhwc_f16: cannot raise the LDS limit");
+            *rc = FD_EHIP;
+            return true;
         }
-        fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 4.0, -1.0, fd_tag(7u, B, HW, C, NT));
-        // grid (B, G / GB), sample fastest (round 4): -10..-20 % on every slab shape against (G / GB, B)
-        // (profiles/r04_session_ab.txt sec. 8: 16x1024x640 17.6 -> 14.0 us, 16x256x1280 10.2 -> 8.3 us)
-        hipLaunchKernelGGL((k_gn_slab<NT, NV>), dim3(B, G / GB), dim3(NT), lds, st, (const half_t*)x,
-                           (half_t*)y, gamma, beta, HW, C, G, GB, eps, silu, ldx);
-        fd_prof_end(FD_FAMILY_GROUPNORM, st);
-        *rc = hipGetLastError() == hipSuccess ? FD_OK : FD_EHIP;
-        if (*rc != FD_OK) fd_set_error("k_gn_slab: launch failed");
-        return true;
     }
-    return false;
+    fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 4.0, -1.0, fd_tag(7u, B, HW, C, NT));
+    // grid (B, G / GB), sample fastest (round 4): -10..-20 % on every slab shape against (G / GB, B)
+    // (profiles/r04_session_ab.txt sec. 8: 16x1024x640 17.6 -> 14.0 us, 16x256x1280 10.2 -> 8.3 us)
+    hipLaunchKernelGGL((k_gn_slab<NT, NV>), dim3(B, G / GB), dim3(NT), lds, st, (const half_t*)x,
+                       (half_t*)y, gamma, beta, HW, C, G, GB, eps, silu, ldx);
+    fd_prof_end(FD_FAMILY_GROUPNORM, st);
+    *rc = hipGetLastError() == hipSuccess ? FD_OK : FD_EHIP;
+    if (*rc != FD_OK) fd_set_error("k_gn_slab: launch failed");
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------

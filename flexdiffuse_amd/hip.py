@@ -48,6 +48,7 @@ _SIGNATURES = {
     'fd_gemm_f16': (c_int, [P, P]),
     'fd_gemm_can_emit_row_stats': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'fd_gemm_plan': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'fd_gemm_can_fuse_groupnorm': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'fd_attention_f16': (c_int, [P, P]),
     'fd_xattn_image_bytes': (c_int64, [c_int, c_int]),
     'fd_xattn_pack_kv_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, P]),

@@ -33,7 +33,9 @@ class fd_gemm_desc(ctypes.Structure):
                 ('tile', c_int32), ('split_k', c_int32), ('workspace', c_void_p),
                 ('workspace_bytes', c_int64), ('ln_stats', c_void_p), ('ln_colsum', c_void_p),
                 ('ln_stats_out', c_void_p), ('ln_eps', c_float), ('A2', c_void_p), ('lda2', c_int32), ('K2', c_int32),
-                ('batch_stride_bias', c_int64)]
+                ('batch_stride_bias', c_int64),
+                ('gn_out', c_void_p), ('gn_gamma', c_void_p), ('gn_beta', c_void_p),
+                ('gn_groups', c_int32), ('gn_silu', c_int32), ('gn_eps', c_float), ('gn_skip_c', c_int32)]
 
 
 class fd_attention_desc(ctypes.Structure):
@@ -272,6 +274,8 @@ def _empty(shape, dtype, like: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------- gemm
 _splitk_ws = {}
 SPLITK_WS_BYTES = 96 << 20
+GN_FINISH_FUSE = os.environ.get('FD_GN_FINISH_FUSE', '1') != '0'   # GroupNorm inside the split-K finish (A/B: 0 = separate launches)
+_last_conv_gn_fused = False
 FORCE_TILE = 0      # debugging / tuning knobs (0 = library cost model)
 FORCE_SPLIT = 0
 WS_SLOT = 0         # scratch-buffer set; work enqueued concurrently on another stream must use another slot
@@ -368,13 +372,27 @@ def bgemm(a: torch.Tensor, w: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
     return out
 
 
+@dataclass
+class GNSpec:
+    '''A GroupNorm(+SiLU) that consumes a convolution's output (conv2d(..., gn=...)).'''
+    gamma: torch.Tensor
+    beta: torch.Tensor
+    G: int
+    eps: float
+    silu: bool
+
+
 def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), up: bool = False,
            out_hw: Optional[Tuple[int, int]] = None, act: int = ACT_NONE,
            residual: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None,
            ld_bias2: int = 0, out_f32: bool = False, out: Optional[torch.Tensor] = None,
-           a2: Optional[torch.Tensor] = None) -> Act:
+           a2: Optional[torch.Tensor] = None, gn: Optional[GNSpec] = None, keep: bool = True):
     '''NHWC conv (kh x kw) as implicit GEMM; `up` fuses a nearest-2x upsample of the input.  `a2` [M][Cx]
-    (row stride free): the rows of the 1x1 shortcut appended to `w` by prep_conv_shortcut.'''
+    (row stride free): the rows of the 1x1 shortcut appended to `w` by prep_conv_shortcut.
+    `gn`: also return GroupNorm(+SiLU) of the output -> (Act or None, Act): where the library splits the convolution over K
+    (the 16x16 / 8x8 UNet levels) the pass that sums the partial slabs normalises them too (fd_gemm_desc.gn_out: one launch
+    less; with keep=False the un-normalised output is never written and the first element is None); everywhere else the
+    convolution is followed by the ordinary groupnorm launch.  Same bits either way.'''
     assert x.C == w.cin, (x.C, w.cin)
     Hv, Wv = (x.H * 2, x.W * 2) if up else (x.H, x.W)
     if out_hw is None:
@@ -417,6 +435,25 @@ def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), 
     else:
         assert a2 is None
     _sched(d, x.t.device)
+    if gn is not None:
+        lib = hip.lib()
+        tile, split = c_int32(0), c_int32(0)
+        hip.check(lib.fd_gemm_plan(ctypes.byref(d), ctypes.byref(tile), ctypes.byref(split)), 'fd_gemm_plan')
+        fuse = (GN_FINISH_FUSE and split.value > 1 and act == ACT_NONE and not out_f32 and w.cout % 8 == 0 and out.stride(0) % 8 == 0
+                and (residual is None or (residual.stride(0) % 8 == 0 and residual.data_ptr() % 16 == 0))
+                and (bias2 is None or (ld_bias2 % 4 == 0 and bias2.data_ptr() % 16 == 0))
+                and lib.fd_gemm_can_fuse_groupnorm(M, w.cout, Ho * Wo, gn.G, split.value))
+        global _last_conv_gn_fused
+        _last_conv_gn_fused = bool(fuse)      # (read by the tests: which form the last conv2d(..., gn=) took)
+        if not fuse:
+            hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+            res = Act(out, x.B, Ho, Wo)
+            return res, groupnorm(res, gn.gamma, gn.beta, gn.G, gn.eps, gn.silu)
+        y = _empty((M, w.cout), torch.float16, x.t)
+        d.gn_out, d.gn_gamma, d.gn_beta = y.data_ptr(), gn.gamma.data_ptr(), gn.beta.data_ptr()
+        d.gn_groups, d.gn_silu, d.gn_eps, d.gn_skip_c = gn.G, int(gn.silu), gn.eps, int(not keep)
+        hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+        return (Act(out, x.B, Ho, Wo) if keep else None), Act(y, x.B, Ho, Wo)
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     return Act(out, x.B, Ho, Wo)
 

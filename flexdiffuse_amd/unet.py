@@ -263,25 +263,41 @@ class UNet2DConditionModel():
         self._ctx_ref = ctx  # keep the tensor alive so its data_ptr cannot be recycled
 
     # ---- blocks -----------------------------------------------------------------------------
-    def _res(self, r: _Res, x: Act, temb: torch.Tensor, out: Optional[torch.Tensor] = None) -> Act:
-        h = ops.groupnorm(x, r.n1g, r.n1b, self.G, 1e-5, True)
-        h = ops.conv2d(h, r.conv1, bias2=temb[:, r.temb_off:r.temb_off + r.cout],
-                       ld_bias2=self.temb_total)
-        h = ops.groupnorm(h, r.n2g, r.n2b, self.G, 1e-5, True)
-        if r.sc_fused:
-            return ops.conv2d(h, r.conv2, a2=x.t, out=out)
-        sc = x.t if r.short is None else ops.gemm(x.t, r.short)
-        return ops.conv2d(h, r.conv2, residual=sc, out=out)
+    def _gn1(self, r: Optional[_Res]) -> Optional[ops.GNSpec]:
+        '''norm1 + SiLU of ResBlock `r` as a spec its input's PRODUCER can take (ops.conv2d(..., gn=)).'''
+        return None if r is None else ops.GNSpec(r.n1g, r.n1b, self.G, 1e-5, True)
 
-    def _attn(self, a: _Attn, x: Act, rep: int = 1, out: Optional[torch.Tensor] = None) -> Act:
+    def _attn_gn(self, a: Optional[_Attn], x: Act) -> Optional[ops.GNSpec]:
+        '''The transformer block's input GroupNorm as a producer-side spec -- only where the block reads a normalised tensor
+        (where the GroupNorm is folded into proj_in, ops.gn_fold_supported, there is nothing to produce).'''
+        if a is None or ops.gn_fold_supported(x.B, x.HW, a.C, a.C, self.G):
+            return None
+        return ops.GNSpec(a.ng, a.nb, self.G, 1e-6, False)
+
+    def _res(self, r: _Res, x: Act, temb: torch.Tensor, out: Optional[torch.Tensor] = None, xn: Optional[Act] = None,
+             next_gn: Optional[ops.GNSpec] = None):
+        '''ResBlock -> (output, GroupNorm `next_gn` of the output or None).  `xn`: norm1 + SiLU of `x` when the producer of x
+        already made it (the split-K finish of the previous convolution); `next_gn`: the normalisation the consumer of this
+        block's output starts with, handed to conv2 the same way.'''
+        h = xn if xn is not None else ops.groupnorm(x, r.n1g, r.n1b, self.G, 1e-5, True)
+        # conv1 feeds nothing but norm2 + SiLU: where the convolution is split over K (16x16 / 8x8 levels) the finish pass of
+        # the split normalises the tile it has just summed (fd_gemm_desc.gn_out) and conv1's own output is never written
+        _, h = ops.conv2d(h, r.conv1, bias2=temb[:, r.temb_off:r.temb_off + r.cout], ld_bias2=self.temb_total,
+                          gn=ops.GNSpec(r.n2g, r.n2b, self.G, 1e-5, True), keep=False)
+        kw = dict(a2=x.t) if r.sc_fused else dict(residual=x.t if r.short is None else ops.gemm(x.t, r.short))
+        if next_gn is None:
+            return ops.conv2d(h, r.conv2, out=out, **kw), None
+        return ops.conv2d(h, r.conv2, out=out, gn=next_gn, keep=True, **kw)
+
+    def _attn(self, a: _Attn, x: Act, rep: int = 1, out: Optional[torch.Tensor] = None, xn: Optional[Act] = None) -> Act:
         '''Transformer block.  rep > 1: `x` holds B samples that are shared by `rep` branches of
         the cached context (CFG: [uncond]*B + cond on the same latents).  Everything up to the
         cross-attention query is branch-independent and computed once; the output has rep*B
-        samples.'''
+        samples.  `xn`: the block's input GroupNorm of `x` when the producer of x already made it (_attn_gn).'''
         B, HW, C = x.B, x.HW, a.C
         d = C // a.heads
         gn_fold = ops.gn_fold_supported(B, HW, C, C, self.G)
-        h = None if gn_fold else ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False)
+        h = None if gn_fold else (xn if xn is not None else ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False))
         # LayerNorm fold: the GEMM that PRODUCES a LayerNorm input also writes its row statistics where one
         # tile spans the row (C == 320: the 64x64 level); elsewhere one read-only statistics pass
         # (C == 320: finished pairs; wider rows: raw partial sums per 160-column tile + a tiny finalise launch)
@@ -420,15 +436,21 @@ class UNet2DConditionModel():
                 push(Act(view, Be, h.H, h.W), buf, ch)
         else:
             h = push(ops.conv2d(x, self.conv_in, out=view), buf, ch)
+        # `pend`: norm1 + SiLU of h for the NEXT ResBlock, made by the split-K finish of h's producer (deep levels; None elsewhere)
+        pend: Optional[Act] = None
+        seq = [r for blk in self.down for r in blk['res']] + [self.mid_res0]      # ResBlocks in execution order
+        nres = 0
         for blk in self.down:
             for r, a in zip(blk['res'], blk['attn']):
                 rows = Be * h.H * h.W
                 buf, view, ch = slot(rows, r.cout)
+                nres += 1
                 if a is not None:
-                    h = self._res(r, h, temb[:h.B])
-                    h = self._attn(a, h, fan, out=view)
+                    h, hn = self._res(r, h, temb[:h.B], xn=pend, next_gn=self._attn_gn(a, h))
+                    pend = None
+                    h = self._attn(a, h, fan, out=view, xn=hn)
                 elif fan > 1:
-                    h = self._res(r, h, temb[:h.B])
+                    h, pend = self._res(r, h, temb[:h.B], xn=pend)
                     if view is None:
                         h = Act(ops.repeat_rows(h.t, fan), Be, h.H, h.W)
                     else:
@@ -436,15 +458,21 @@ class UNet2DConditionModel():
                             ops.copy_rows(view[f * h.B * h.HW:(f + 1) * h.B * h.HW], h.t)
                         h = Act(view, Be, h.H, h.W)
                 else:
-                    h = self._res(r, h, temb[:h.B], out=view)
+                    # the next ResBlock reads exactly this tensor (no attention in between): its norm1 rides in conv2's finish
+                    nxt = seq[nres] if blk['down'] is None or r is not blk['res'][-1] else None
+                    h, pend = self._res(r, h, temb[:h.B], out=view, xn=pend, next_gn=self._gn1(nxt))
                 fan = 1
                 push(h, buf, ch)
             if blk['down'] is not None:
                 buf, view, ch = slot(Be * (h.H // 2) * (h.W // 2), blk['down'].cout)
-                h = push(ops.conv2d(h, blk['down'], stride=2, out=view), buf, ch)
-        h = self._res(self.mid_res0, h, temb)
-        h = self._attn(self.mid_attn, h)
-        h = self._res(self.mid_res1, h, temb, out=left(h.B * h.HW, self.mid_res1.cout))
+                if blk['down'].im2col:
+                    h, pend = ops.conv2d(h, blk['down'], stride=2, out=view), None
+                else:
+                    h, pend = ops.conv2d(h, blk['down'], stride=2, out=view, gn=self._gn1(seq[nres]), keep=True)
+                push(h, buf, ch)
+        h, hn = self._res(self.mid_res0, h, temb, xn=pend, next_gn=self._attn_gn(self.mid_attn, h))
+        h = self._attn(self.mid_attn, h, xn=hn)
+        h, _ = self._res(self.mid_res1, h, temb, out=left(h.B * h.HW, self.mid_res1.cout))
         for blk in self.up:
             n = len(blk['res'])
             for j, (r, a) in enumerate(zip(blk['res'], blk['attn'])):
@@ -458,10 +486,10 @@ class UNet2DConditionModel():
                 last = j == n - 1
                 dst = None if (last and blk['up'] is not None) else left(h.B * h.HW, r.cout)
                 if a is not None:
-                    h = self._res(r, h, temb)
-                    h = self._attn(a, h, out=dst)
+                    h, hn = self._res(r, h, temb, next_gn=self._attn_gn(a, h))
+                    h = self._attn(a, h, out=dst, xn=hn)
                 else:
-                    h = self._res(r, h, temb, out=dst)
+                    h, _ = self._res(r, h, temb, out=dst)
             if blk['up'] is not None:
                 dst = left(h.B * h.HW * 4, blk['up'].cout)
                 if blk.get('up_ph') is not None and h.t.is_contiguous() and ops.up_phases_supported(h.B * h.HW, blk['up'].cout, blk['up'].cin):

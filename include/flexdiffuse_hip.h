@@ -223,6 +223,20 @@ typedef struct fd_gemm_desc {
      * multiplied by ITS weights and get ITS bias.  LDS-DMA path with LDS-staged biases only.  With batch > 1,
      * ln_stats_out needs batch_stride_c == M * ldc (row index = batch * M + m). */
     int64_t batch_stride_bias;
+    /* (ABI 11) GroupNorm(+SiLU) of the OUTPUT fused into the split-K finish pass: gn_out [M][N] (contiguous fp16) =
+     * act(GroupNorm_{gn_groups}(C; gn_gamma, gn_beta, gn_eps)) over the rows_per_sample rows x N / gn_groups channels of each
+     * (sample, group), statistics of the fp16-rounded values of C -- bit for bit what fd_groupnorm_nhwc_f16 gives on C.  Inside
+     * `unet(...)` (reference pipeline/guide.py:56-58) a ResBlock's conv1 feeds nothing but norm2 + SiLU (diffusers ResnetBlock2D):
+     * at the 16x16 / 8x8 levels, where the convolution is split over K, the pass that sums the fp32 partial slabs normalises the
+     * tile it has just summed -- one launch less, and with gn_skip_c the convolution's own output never goes to HBM (C may then be
+     * NULL).  Only honoured by split-K launches (ask fd_gemm_plan for the split, fd_gemm_can_fuse_groupnorm for the shape);
+     * FD_ESHAPE otherwise.  act NONE, fp16 output, batch 1; residual row stride % 8 == 0.  NULL = off. */
+    void* gn_out;
+    const float* gn_gamma; /* [N] */
+    const float* gn_beta;  /* [N] */
+    int32_t gn_groups, gn_silu;
+    float gn_eps;
+    int32_t gn_skip_c;
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);
@@ -235,6 +249,10 @@ int fd_gemm_can_emit_row_stats(int M, int N, int K, int ldc, int ldr);
  * Tile ids as in fd_gemm_desc.tile (30..33: the ping-pong kernels of gemm_pp.hip; -7: the 128x128 generic kernel with the
  * LayerNorm fold compiled in).  Pointers are only tested for NULL / alignment. */
 int fd_gemm_plan(const fd_gemm_desc* d, int* tile, int* split_k);
+/* (ABI 11) 1 when a split-K launch of an [M][N] output with `rows_per_sample` rows per sample and split factor `split_k` can take
+ * fd_gemm_desc.gn_out with `groups` groups (the slab of one sample x a few groups fits the finish kernel's registers); 0: run
+ * fd_groupnorm_nhwc_f16 on the output instead.  Host logic only. */
+int fd_gemm_can_fuse_groupnorm(int M, int N, int rows_per_sample, int groups, int split_k);
 
 /* Flash attention forward (scores never leave registers).  Q [B][n_q][ldq], K [B][n_k][ldk]
  * with head h at column h*head_dim; Vt [B][heads*head_dim][ldvt] is V transposed (keys

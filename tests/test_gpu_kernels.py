@@ -849,3 +849,157 @@ def test_per_batch_bias_is_refused_where_it_cannot_be_staged(dev):
     bb = torch.zeros((1, 64), dtype=torch.float32, device=dev)
     with pytest.raises(ValueError):
         ops.gemm_per_sample(a, wb, bb, 1, 512)      # batch_stride_bias needs batch > 1
+
+
+@pytest.mark.parametrize('B,H,C,Cx,keep', [(16, 8, 1280, 0, False), (16, 16, 1280, 0, False), (16, 16, 1280, 0, True), (16, 8, 1280, 2560, True),
+                                          (16, 16, 1280, 2560, True), (2, 24, 1280, 0, False), (4, 12, 1280, 0, True)])
+def test_groupnorm_fused_into_the_splitk_finish(dev, B, H, C, Cx, keep):
+    '''fd_gemm_desc.gn_out: the pass that sums a split-K convolution's fp32 slabs also normalises them (ResBlock conv1 -> norm2 +
+    SiLU at the 16x16 / 8x8 levels; with Cx the convolution carries an appended shortcut and the un-normalised output is kept, the
+    conv2 -> next block's norm form).  Against (a) the two launches it replaces -- same bits, for the output and for the normalised
+    tensor --, (b) a torch fp32 reference of conv + per-sample bias + GroupNorm + SiLU on the same fp16-rounded output, (c) itself,
+    20 times.'''
+    from flexdiffuse_amd import ops
+    G, eps, silu = 32, 1e-5, True
+    g = torch.Generator().manual_seed(B * H + C + Cx)
+    M = B * H * H
+    hx = (torch.randn((B, C, H, H), generator=g) * 0.7).half()
+    w = torch.randn((C, C, 3, 3), generator=g) * (9 * C) ** -0.5
+    b = torch.randn(C, generator=g) * 0.1
+    temb = (torch.randn((B, C + 64), generator=g) * 0.5).to(dev)      # per-sample bias rows inside a wider matrix
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.3 * torch.randn(C, generator=g)).to(dev)
+    hd = ops.Act(hx.permute(0, 2, 3, 1).reshape(M, C).contiguous().to(dev), B, H, H)
+    spec = ops.GNSpec(gamma, beta, G, eps, silu)
+    kw = dict(bias2=temb[:, 32:32 + C], ld_bias2=C + 64)
+    if Cx:
+        x = (torch.randn((M, Cx), generator=g) * 0.7).half().to(dev)
+        ws, bs = torch.randn((C, Cx), generator=g) * Cx ** -0.5, torch.randn(C, generator=g) * 0.1
+        cw = ops.prep_conv_shortcut(w, b, ws, bs, dev)
+        kw = dict(a2=x)
+    else:
+        cw = ops.prep_conv(w, b, dev)
+    assert ops.GN_FINISH_FUSE
+    out_f, y_f = ops.conv2d(hd, cw, gn=spec, keep=keep, **kw)
+    # the launch really is a split-K one (otherwise both paths here are the same two launches)
+    assert ops._last_conv_gn_fused is True and (out_f is not None) == keep
+    ops.GN_FINISH_FUSE = False
+    try:
+        out_u, y_u = ops.conv2d(hd, cw, gn=spec, keep=keep, **kw)
+    finally:
+        ops.GN_FINISH_FUSE = True
+    assert ops._last_conv_gn_fused is False
+    assert torch.equal(y_f.t, y_u.t), float((y_f.t.float() - y_u.t.float()).abs().max())
+    if keep:
+        assert torch.equal(out_f.t, out_u.t)
+    # (b) torch fp32 on the fp16-rounded convolution output
+    h16 = out_u.t.float().view(B, H * H, C).permute(0, 2, 1).reshape(B, C, H, H)
+    want = F.silu(F.group_norm(h16, G, gamma.float(), beta.float(), eps))
+    close(y_f.t.float().view(B, H * H, C).permute(0, 2, 1).reshape(B, C, H, H), want, rtol=4e-3, atol=4e-3)
+    # (c) repeats bit for bit
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(20):
+        _, y2 = ops.conv2d(hd, cw, gn=spec, keep=keep, **kw)
+        bad += (y2.t != y_f.t).sum()
+    assert int(bad) == 0
+
+
+def test_groupnorm_finish_fusion_is_refused_where_it_cannot_run(dev):
+    '''gn_out on a launch the rule does not split is FD_ESHAPE (the Python front asks fd_gemm_plan first and never gets there);
+    fd_gemm_can_fuse_groupnorm answers for shapes and split factors.'''
+    import ctypes
+    from flexdiffuse_amd import hip, ops
+    lib = hip.lib()
+    assert lib.fd_gemm_can_fuse_groupnorm(1024, 1280, 64, 32, 8) == 1 and lib.fd_gemm_can_fuse_groupnorm(4096, 1280, 256, 32, 4) == 1
+    assert lib.fd_gemm_can_fuse_groupnorm(4096, 1280, 256, 32, 1) == 0 and lib.fd_gemm_can_fuse_groupnorm(4096, 1280, 256, 32, 3) == 0
+    assert lib.fd_gemm_can_fuse_groupnorm(65536, 320, 4096, 32, 2) == 0          # a 64x64 slab does not fit the finish kernel's registers
+    assert lib.fd_gemm_can_fuse_groupnorm(1024, 1280, 60, 32, 8) == 0             # rows_per_sample does not divide M
+    B, H, C = 2, 64, 320                                                           # level-0 shape: never split
+    g = torch.Generator().manual_seed(5)
+    hd = ops.Act((torch.randn((B * H * H, C), generator=g) * 0.5).half().to(dev), B, H, H)
+    cw = ops.prep_conv(torch.randn((C, C, 3, 3), generator=g) * 0.02, torch.zeros(C), dev)
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    out, y = ops.conv2d(hd, cw, gn=ops.GNSpec(gamma, beta, 32, 1e-5, True))       # falls back to two launches
+    want = F.silu(F.group_norm(out.t.float().view(B, H * H, C).permute(0, 2, 1).reshape(B, C, H, H), 32, gamma, beta, 1e-5))
+    close(y.t.float().view(B, H * H, C).permute(0, 2, 1).reshape(B, C, H, H), want, rtol=4e-3, atol=4e-3)
+    # a shape whose slab fits the finish kernel but that the rule does not split (64 x 16 x 16 x 1280: 256 full tiles)
+    B, H, C = 64, 16, 1280
+    assert lib.fd_gemm_can_fuse_groupnorm(B * H * H, C, H * H, 32, 2) == 1
+    hd = ops.Act((torch.randn((B * H * H, C), generator=g) * 0.5).half().to(dev), B, H, H)
+    cw = ops.prep_conv(torch.randn((C, C, 3, 3), generator=g) * 0.01, torch.zeros(C), dev)
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    out, y = ops.conv2d(hd, cw, gn=ops.GNSpec(gamma, beta, 32, 1e-5, True))
+    d = ops.fd_gemm_desc()
+    d.A, d.W, d.C, d.bias = hd.t.data_ptr(), cw.w.data_ptr(), out.t.data_ptr(), cw.bias.data_ptr()
+    d.M, d.N, d.K, d.ldw, d.ldc, d.lda = B * H * H, C, cw.kpad, cw.w.stride(0), C, C
+    d.rows_per_sample, d.alpha, d.batch = H * H, 1.0, 1
+    d.conv, d.in_h, d.in_w, d.in_c, d.out_h, d.out_w, d.kh, d.kw, d.stride, d.pad_t, d.pad_l = 1, H, H, C, H, H, 3, 3, 1, 1, 1
+    ops._sched(d, dev)
+    tile, split = ctypes.c_int32(0), ctypes.c_int32(0)
+    hip.check(lib.fd_gemm_plan(ctypes.byref(d), ctypes.byref(tile), ctypes.byref(split)), 'fd_gemm_plan')
+    assert split.value == 1
+    d.gn_out, d.gn_gamma, d.gn_beta, d.gn_groups, d.gn_silu, d.gn_eps = y.t.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 32, 1, 1e-5
+    with pytest.raises(ValueError, match='split-K'):
+        hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+
+
+def test_persistent_geglu_tile_race_screen_with_weights_streaming_from_hbm(dev):
+    '''The race screen of test_lds_dma_tiles_race_screen_with_weights_streaming_from_hbm for the kernel that serves the GEGLU
+    launches of the forward: the PERSISTENT 256x256 / 16-wave tile with the LayerNorm-fold + GEGLU epilogue
+    (`k_gemm_f16_dmap<256, 256, ..., 6>`): the next tile's first K-tile is in flight under the epilogue, its counted waits are the
+    only thing between an LDS-DMA and the ds_read of its piece.  52 MB of weights, every tile reads its own rows once (every W DMA is
+    an HBM miss), K = 320 as at level 0; vs torch, then 400 launches bit for bit.'''
+    from flexdiffuse_amd import ops
+    M, N, K = 512, 81920, 320
+    g = torch.Generator().manual_seed(23)
+    x = (torch.randn((M, K), generator=g) * 0.8 + 0.3).half()
+    w = torch.randn((N, K), generator=g) * K ** -0.5
+    bias = torch.randn(N, generator=g) * 0.1
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    lw = ops.prep_linear_ln(w, bias, gamma, beta, dev, geglu=True)
+    xd = x.to(dev)
+    st = ops.ln_row_stats(xd)
+    import ctypes
+    from flexdiffuse_amd import hip
+    ref = ops.gemm(xd, lw, act=ops.ACT_GEGLU, ln_stats=st).clone()
+    torch.cuda.synchronize()
+    hdn = F.layer_norm(x.float().to(dev), (K,), gamma.to(dev), beta.to(dev), 1e-5) @ w.to(dev).t() + bias.to(dev)
+    want = hdn[:, :N // 2] * F.gelu(hdn[:, N // 2:])
+    err = float((ref.float() - want).abs().max())
+    assert err < 2e-2 * max(1.0, float(want.abs().max())), err
+    out = torch.empty_like(ref)
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(400):
+        ops.gemm(xd, lw, act=ops.ACT_GEGLU, ln_stats=st, out=out)
+        bad += (out != ref).sum()
+    torch.cuda.synchronize()
+    assert int(bad) == 0, int(bad)
+
+
+@pytest.mark.parametrize('B,HW,rep,d', [(16, 4096, 2, 40), (16, 1024, 2, 80)])
+def test_fused_cross_attention_race_screen(dev, B, HW, rep, d):
+    '''400 launches of fd_xattn_q_f16 (`k_xattn<40>` / `k_xattn<80>`) at the shapes of the bench forward -- 16 x 64 x 64 x 320
+    and 16 x 32 x 32 x 640 hidden states streaming from HBM through its LDS-DMA ring, two context replicas -- must repeat the first
+    launch bit for bit (the numerics of the kernel are test_fused_q_projection_cross_attention's subject).'''
+    from flexdiffuse_amd import ops
+    heads, L = 8, 77
+    C, M = heads * d, B * HW
+    g = torch.Generator().manual_seed(B + HW + d)
+    xd = (torch.randn((M, C), generator=g) * 1.5 + 0.5).half().to(dev)
+    lw = ops.prep_linear_ln(torch.randn((C, C), generator=g) * C ** -0.5 * ops.QK_LOG2E * d ** -0.5, None,
+                            1 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g), dev)
+    kd = (torch.randn((rep * B * L, C), generator=g) * 1.2).half().to(dev)
+    ldv = (L + 7) // 8 * 8
+    vt = torch.zeros((rep * B, C, ldv), dtype=torch.float16)
+    vt[:, :, :L] = torch.randn((rep * B, C, L), generator=g).half()
+    st = ops.ln_row_stats(xd)
+    assert ops.xattn_supported(heads, d, L, HW)
+    img = ops.xattn_pack_kv(kd, vt.to(dev), rep * B, L, heads, d)
+    ref = ops.xattn_q(xd, lw, st, img, HW, L, heads, d, n_rep=rep).clone()
+    assert bool(torch.isfinite(ref.float()).all()) and float(ref.float().abs().max()) > 0.1
+    out = torch.empty_like(ref)
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(400):
+        ops.xattn_q(xd, lw, st, img, HW, L, heads, d, n_rep=rep, out=out)
+        bad += (out != ref).sum()
+    torch.cuda.synchronize()
+    assert int(bad) == 0, int(bad)

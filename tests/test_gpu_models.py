@@ -926,6 +926,38 @@ def test_launch_plan_replay_matches_eager_front(mini, dev):
     assert not torch.equal(plan[0], plan[1]) and torch.equal(plan[0], plan[2])
 
 
+def test_sd15_denoising_loop_determinism_soak(sd15, dev):
+    '''20 passes of the headline request (SD1.5 512x512, 50 DDIM steps, CFG batch 16, HIP-graph replay = the product default and
+    the mode bench.py times): 1000 CFG forwards = ~300 k launches of every counted-wait kernel of the forward (ping-pong /
+    3-stage / persistent GEMM tiles, k_xattn, the split-K finish) must reproduce the first pass bit for bit, and one pass through
+    the launch plan must give the same bits.  Round 5's missing phase-3 wait of the ping-pong loop (one launch in 25,000 read a
+    stale LDS piece) fails here within a few passes; it was found by luck in a parity test (tools/soak_determinism.py is the
+    265-pass form of this test).'''
+    import bench
+    from flexdiffuse_amd import Guide, SimpleGuide
+    from flexdiffuse_amd import dist as fdist
+    from flexdiffuse_amd.encode.clip import CLIPEncoder
+    sds, pipe, clip, tok, _ = sd15
+    B, size, steps, passes = 8, 512, 50, 20
+    emb = Guide(clip, tok, device='cuda').embeds(prompt=bench.synth_prompts(B), guide=bench.synth_image(2, 512, 512), **bench.GUIDANCE['linear'])
+    enc = CLIPEncoder(clip, tok)
+    noise = fdist.global_noise(B, (4, size // 8, size // 8), 1337)
+
+    def one():
+        pipe(guide=SimpleGuide(enc, pipe.unet, 8.0, steps, emb), init_size=(size, size), latents=noise, output_type='np')
+        return pipe.last_latents.clone()
+    assert pipe.use_graph
+    ref = one()
+    assert pipe.graph_fallback is None and bool(torch.isfinite(ref).all())
+    differ = [i for i in range(1, passes) if not torch.equal(one(), ref)]
+    assert not differ, f'graph-replay passes {differ} of {passes} differ from the first'
+    try:
+        pipe.use_graph = False
+        assert torch.equal(one(), ref), 'the launch plan and the graph replay differ'
+    finally:
+        pipe.use_graph = True
+
+
 def test_launch_plan_full_size_unet_step(sd15, dev):
     """The recorded plan of the full-size SD1.5 UNet (CFG batch 2 x 2 at 64x64 latents: shared CFG
     prefix, in-place skip concats, LayerNorm-fold statistics, split-K deep levels) replays
