@@ -276,6 +276,7 @@ _splitk_ws = {}
 SPLITK_WS_BYTES = 96 << 20
 GN_FINISH_FUSE = os.environ.get('FD_GN_FINISH_FUSE', '1') != '0'   # GroupNorm inside the split-K finish (A/B: 0 = separate launches)
 _last_conv_gn_fused = False
+gn_fused_launches = 0       # conv2d(..., gn=) calls that took the fused form so far (tests, tools)
 FORCE_TILE = 0      # debugging / tuning knobs (0 = library cost model)
 FORCE_SPLIT = 0
 WS_SLOT = 0         # scratch-buffer set; work enqueued concurrently on another stream must use another slot
@@ -443,8 +444,9 @@ def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), 
                 and (residual is None or (residual.stride(0) % 8 == 0 and residual.data_ptr() % 16 == 0))
                 and (bias2 is None or (ld_bias2 % 4 == 0 and bias2.data_ptr() % 16 == 0))
                 and lib.fd_gemm_can_fuse_groupnorm(M, w.cout, Ho * Wo, gn.G, split.value))
-        global _last_conv_gn_fused
+        global _last_conv_gn_fused, gn_fused_launches
         _last_conv_gn_fused = bool(fuse)      # (read by the tests: which form the last conv2d(..., gn=) took)
+        gn_fused_launches += int(bool(fuse))
         if not fuse:
             hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
             res = Act(out, x.B, Ho, Wo)

@@ -958,6 +958,30 @@ def test_sd15_denoising_loop_determinism_soak(sd15, dev):
         pipe.use_graph = True
 
 
+def test_unet_producer_side_groupnorm_equals_separate_launches(sd15, dev):
+    '''Full-size SD1.5 forward (CFG batch 16 at 64x64 latents, the bench's shape): the GroupNorms that read a split-K convolution's
+    output -- a ResBlock's norm2 behind conv1, the next block's input norm behind conv2 / the downsample convolution, at the 16x16 and 8x8
+    levels -- ride in that convolution's finish pass (fd_gemm_desc.gn_out, unet._res / _attn `xn`).  Same bits as with the GroupNorms
+    launched on their own (ops.GN_FINISH_FUSE = False), 21 launches fewer.'''
+    from flexdiffuse_amd import ops
+    sds, pipe, clip, tok, _ = sd15
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((8, 4, 64, 64), generator=g).to(dev)
+    ctx = torch.randn((16, 77, 768), generator=g).half().to(dev)
+    n0 = ops.gn_fused_launches
+    a = pipe.unet.forward_nhwc(x, 321, ctx, rep=2).clone()
+    fused = ops.gn_fused_launches - n0
+    ops.GN_FINISH_FUSE = False
+    try:
+        b = pipe.unet.forward_nhwc(x, 321, ctx, rep=2).clone()
+        assert ops.gn_fused_launches - n0 == fused
+    finally:
+        ops.GN_FINISH_FUSE = True
+    print(f'GroupNorms inside a split-K finish pass per forward: {fused}')
+    assert fused >= 18, fused
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
 def test_launch_plan_full_size_unet_step(sd15, dev):
     """The recorded plan of the full-size SD1.5 UNet (CFG batch 2 x 2 at 64x64 latents: shared CFG
     prefix, in-place skip concats, LayerNorm-fold statistics, split-K deep levels) replays
