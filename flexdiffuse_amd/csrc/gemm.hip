@@ -517,6 +517,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
         gemm_epilogue_fast<MI, NI, FD_ACT_NONE, EPI == 9, true, false, true, WN>(
             g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN),
             reinterpret_cast<float*>(smem), wm * WTM + fr, wn, m0);
+    } else if constexpr (EPI == 11 || EPI == 12) {   // lean (+ residual) + GroupNorm partial sums of the tile's output (gn_part_out)
+        if constexpr (NS == 3) __syncthreads();
+        gemm_epilogue_fast<MI, NI, FD_ACT_NONE, EPI == 12, true, false, false, WN, WM>(
+            g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN),
+            reinterpret_cast<float*>(smem), wm * WTM + fr, wn, m0);
     } else
         gemm_epilogue_fast<MI, NI, (EPI == 3 || EPI == 6) ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, true, (EPI == 5 || EPI == 6)>(
             g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN));
@@ -1026,6 +1031,18 @@ static int launch_epi(GemmArgs& g, int batch, hipStream_t st) {
     const bool full = g_fast_epi && g.split_k == 1 && !g.out_f32 && !g.trans_out && g.bias_lds &&
                       g.M % BM == 0 && g.N % BN == 0 && (g.ldc & 7) == 0 &&
                       (!g.bias2 || g.rows_per_batch % BM == 0);
+    if (g.gn_part_out) {
+        // GroupNorm partial sums of the output: the 256x320 tile spanning the row, inside one sample, lean epilogue
+        if constexpr (BN == 320 && NS == 2) {
+            if (full && g.act == FD_ACT_NONE && !g.ln_stats && !g.ln_stats_out && g.N == BN && g.rows_per_batch % BM == 0 && !g.phase && batch == 1 &&
+                (!g.res || (g.ldr & 3) == 0)) {
+                if (g.res) return launch<BM, BN, false, WM, NS, WN, 12>(g, batch, st);
+                return launch<BM, BN, false, WM, NS, WN, 11>(g, batch, st);
+            }
+        }
+        fd_set_error("fd_gemm_f16: gn_part_out needs full 320-wide tiles inside one sample and the lean plain / residual epilogue");
+        return FD_ESHAPE;
+    }
     if (g.ln_stats_out) {
         // row statistics of the output: only tiles that span the whole row (N == BN), lean epilogue
         if constexpr ((ALLOW & 256) != 0) {
@@ -1110,6 +1127,26 @@ extern "C" int fd_gemm_can_emit_row_stats(int M, int N, int K, int ldc, int ldr)
 }
 
 static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice);
+
+// Rows of the tile (= rows per chunk of the partial sums) when the launch of `g` on (tile, split) can emit GroupNorm partial sums
+// of its output (fd_gemm_desc.gn_part_out): a tile that spans the row (N == 320: the 256x320 tiles 16 / 30, the 128x320 tile 32) and lies
+// inside one sample, lean plain / residual epilogue; 0 otherwise.  The launchers check the same conditions.
+static int gn_parts_bm(const GemmArgs& g, int tile, int split, int batch) {
+    const int bm = (tile == 16 || tile == 30) ? 256 : (tile == 32 ? 128 : 0);
+    if (!bm || split != 1 || batch != 1 || g.N != 320 || !g_fast_epi || !g.bias_lds || !g_use_dma) return 0;
+    if (g.out_f32 || g.trans_out || g.act != FD_ACT_NONE || g.ln_stats || g.ln_stats_out || g.phase || g.gn_out) return 0;
+    if ((g.ldc & 7) || (g.res && (g.ldr & 3)) || g.M % bm || g.rows_per_batch % bm || g.M % g.rows_per_batch) return 0;
+    if (g.bias2 && g.rows_per_batch % bm) return 0;
+    if (g.gn_groups <= 0 || g.gn_groups > 128 || g.N % g.gn_groups || ((g.N / g.gn_groups) & 1)) return 0;
+    return bm;
+}
+
+extern "C" int fd_gemm_gn_parts_chunks(const fd_gemm_desc* d) {
+    int choice[3] = {-1, 0, 0};
+    if (!d || gemm_impl(d, nullptr, choice) != FD_OK || choice[2] <= 0) return 0;
+    const int rows = d->rows_per_sample > 0 ? d->rows_per_sample : d->M;
+    return rows / choice[2];
+}
 
 extern "C" int fd_gemm_f16(const fd_gemm_desc* d, void* stream) {
     if (fd_plan_recording() && d) {
@@ -1237,6 +1274,10 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
         g.gn_out = (half_t*)d->gn_out; g.gn_gamma = d->gn_gamma; g.gn_beta = d->gn_beta;
         g.gn_groups = d->gn_groups; g.gn_silu = d->gn_silu; g.gn_skip_c = d->gn_skip_c;
         g.gn_eps = d->gn_eps > 0.f ? d->gn_eps : 1e-5f;
+    }
+    if (d->gn_part_out || (choice && choice[0] == -1)) {
+        g.gn_groups = d->gn_groups;
+        g.gn_part_out = d->gn_part_out;
     }
     hipStream_t st = (hipStream_t)stream;
     // priced at the ALGORITHMIC work of the op it implements: the phase-decomposed upsample convolution (batch 4, K = 4 Cin)
@@ -1527,10 +1568,15 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
     if (g.ln_stats && !(best_tile == 9 || best_tile == 10 || (best_tile >= 12 && best_tile <= 16) || best_tile == 20 || best_tile == 23 || best_tile >= 30))
         best_tile = best_tile == 4 ? 4 : -7;     // (reported by fd_gemm_plan as -7: the 128x128 generic kernel with the fold compiled in)
     if (choice) {
+        if (choice[0] == -1) choice[2] = gn_parts_bm(g, best_tile, best_split, batch);   // fd_gemm_gn_parts_chunks
         choice[0] = best_tile;
         choice[1] = best_split;
         return FD_OK;
     }
+    if (g.gn_part_out)
+        FD_CHECK_ARG(gn_parts_bm(g, best_tile, best_split, batch) > 0 && (uintptr_t)g.gn_part_out % 8 == 0, FD_ESHAPE,
+                     "fd_gemm_f16: gn_part_out cannot be honoured by tile %d x split %d of M=%d N=%d (rows per sample %d, %d groups); ask fd_gemm_gn_parts_chunks first",
+                     best_tile, best_split, g.M, g.N, g.rows_per_batch, g.gn_groups);
     if (g.gn_out)
         FD_CHECK_ARG(best_split == 2 || best_split == 4 || best_split == 8 || best_split == 16, FD_ESHAPE,
                      "fd_gemm_f16: gn_out is honoured by split-K launches only (this one: tile %d, split_k %d); ask fd_gemm_plan first", best_tile, best_split);

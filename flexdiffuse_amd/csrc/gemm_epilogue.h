@@ -53,6 +53,9 @@ struct GemmArgs {
     const float* gn_beta;
     int gn_groups, gn_silu, gn_gb, gn_skip_c;   // gn_gb: groups per workgroup (gn_slab_pick)
     float gn_eps;
+    // GroupNorm partial sums of the OUTPUT from the lean epilogue of a row-spanning tile (fd_gemm_desc.gn_part_out):
+    // [sample][rows_per_batch / BM][gn_groups][2] = (sum, sum of squares) of the fp16-rounded values, the layout k_gn_stats writes
+    float* gn_part_out;
 };
 
 // Exact-form GELU  x * Phi(x),  Phi(x) = 0.5 * (1 + erf(x / sqrt 2)),  with erf from Abramowitz &
@@ -150,7 +153,7 @@ __device__ __forceinline__ void epi_store16(half_t* p, u32x4 v) {
 // 3 GEGLU): with both epilogues inlined in one kernel the 16-wave persistent kernels (128-VGPR
 // cap) spill ~500 bytes per lane to scratch and run 2x slower.  The host picks EPI != 0 only when
 // every tile of the launch is full and the biases are LDS-staged (launch_epi).
-template <int MI, int NI, int ACT, bool RES, bool B2, bool LNF = false, bool STATS = false, int WN_ = 1>
+template <int MI, int NI, int ACT, bool RES, bool B2, bool LNF = false, bool STATS = false, int WN_ = 1, int GNP_WM = 0>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&acc)[MI][NI], int row0,
                                                    int col0, int coll, int fq, int z,
                                                    lds_cfloat bias_tile, lds_cfloat bias2_tile,
@@ -240,6 +243,11 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
         const half_t* Rb = RES ? g.res + (size_t)z * g.strideRes + (size_t)row0 * g.ldr + col0 + fq * 4 : nullptr;
         floatx2 st_next = {g.alpha, 0.f};   // LNF: one row block ahead (see the GEGLU branch)
         if constexpr (LNF) st_next = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)row0);
+        // GNP_WM > 0 (the tile spans the row, N == BN, and lies inside one sample): GroupNorm partial sums of the tile's output per
+        // COLUMN PAIR, from the fp16-rounded values, with v_dot2_f32_f16 (a pair never straddles two groups: N / groups is even)
+        float gsum[GNP_WM ? NI : 1][2], gsq[GNP_WM ? NI : 1][2];
+#pragma unroll
+        for (int j = 0; j < (GNP_WM ? NI : 1); ++j) gsum[j][0] = gsum[j][1] = gsq[j][0] = gsq[j][1] = 0.f;
         // (the residual rows one block ahead as well: measured neutral and 2-3 spilled VGPRs on the 256x320 tile -- not kept)
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -292,6 +300,19 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
                 s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
                 if (fq == 0) *reinterpret_cast<floatx2*>(xch + ((trow0 + i * 16) * WN_ + wn) * 2) = floatx2{s1, s2};
             }
+            if constexpr (GNP_WM > 0) {
+                const half2v one2 = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    // (the two halves spelled out element by element: through bit_cast(u32x2, oh[j])[p] hipcc treated both halves as
+                    // one value and emitted half of the dot products)
+                    const half2v h01 = {oh[j][0], oh[j][1]}, h23 = {oh[j][2], oh[j][3]};
+                    gsum[j][0] = __builtin_amdgcn_fdot2(h01, one2, gsum[j][0], false);
+                    gsq[j][0] = __builtin_amdgcn_fdot2(h01, h01, gsq[j][0], false);
+                    gsum[j][1] = __builtin_amdgcn_fdot2(h23, one2, gsum[j][1], false);
+                    gsq[j][1] = __builtin_amdgcn_fdot2(h23, h23, gsq[j][1], false);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NI; j += 2) {
                 if (j + 1 < NI) {
@@ -306,6 +327,42 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
                 }
             }
             __builtin_amdgcn_sched_barrier(0);   // see the GEGLU branch
+        }
+        if constexpr (GNP_WM > 0) {
+            // (1) the 16 rows of a fragment column live in the 16 lanes of a lane group: butterfly over lane bits 0..3;
+            // (2) one slot per (wave row, column pair) in LDS (the K loop's stages are dead: the kernels synchronise before an
+            //     epilogue that writes `xch`); (3) thread (group, stat) sums its wave rows and its N / groups / 2 pairs in a fixed
+            //     order and writes the tile's partial: [sample][chunk = tile row inside the sample][group][2]
+            constexpr int PAIRS = WN_ * NI * 8;   // column pairs of the tile (BN / 2)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        gsum[j][p] += __shfl_xor(gsum[j][p], o, 64);
+                        gsq[j][p] += __shfl_xor(gsq[j][p], o, 64);
+                    }
+            const int wm_ = trow0 / (MI * 16);
+            if ((threadIdx.x & 15) == 0) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        *reinterpret_cast<floatx2*>(xch + (wm_ * PAIRS + ((coll + j * 16 + fq * 4) >> 1) + p) * 2) = floatx2{gsum[j][p], gsq[j][p]};
+            }
+            __syncthreads();
+            const int G = g.gn_groups, ppg = (g.N / G) >> 1, t = threadIdx.x;
+            if (t < 2 * G) {
+                const int gi = t >> 1, stt = t & 1;
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < GNP_WM; ++w)
+                    for (int p = 0; p < ppg; ++p) a += xch[(w * PAIRS + gi * ppg + p) * 2 + stt];
+                constexpr int BM_ = GNP_WM * MI * 16;
+                const int b = m0 / g.rows_per_batch, chunk = (m0 - b * g.rows_per_batch) / BM_, nchunk = g.rows_per_batch / BM_;
+                g.gn_part_out[(((size_t)b * nchunk + chunk) * G + gi) * 2 + stt] = a;
+            }
         }
         if constexpr (STATS) {
             // combine the WN_ wave slots of each row and finalise: one lane per row (waves with wn == 0)

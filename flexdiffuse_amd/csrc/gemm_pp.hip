@@ -405,6 +405,14 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
         gemm_epilogue_fast<MI, NI, FD_ACT_NONE, EPI == 9, true, false, true, WN_>(
             g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN),
             reinterpret_cast<float*>(smem), wm * WTM + fr, wn, m0);
+    } else if constexpr (EPI == 11 || EPI == 12) {
+        // lean (11) / lean + residual (12) with the GroupNorm partial sums of the tile's output (fd_gemm_desc.gn_part_out): the exchange
+        // buffer reuses the ring, as for the row statistics above
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        gemm_epilogue_fast<MI, NI, FD_ACT_NONE, EPI == 12, true, false, false, WN_, WM_>(
+            g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN),
+            reinterpret_cast<float*>(smem), wm * WTM + fr, wn, m0);
     } else
         gemm_epilogue_fast<MI, NI, (EPI == 3 || EPI == 6) ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, true, (EPI == 5 || EPI == 6)>(
             g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN));
@@ -453,7 +461,7 @@ template <int WM_, int WN_, int MI, int NI, bool CONV, int EPI>
 static int pp_launch_k(GemmArgs& g, int batch, hipStream_t st) {
     // the appended phase exists for the plain / residual / split-K epilogues of convolutions (ResBlock shortcut) and linears
     // (proj_out folded through FF-out)
-    if constexpr (EPI == 1 || EPI == 2 || EPI == 10 || EPI == 0) {
+    if constexpr (EPI == 1 || EPI == 2 || EPI == 10 || EPI == 0 || EPI == 11 || EPI == 12) {
         if (g.K2) return pp_launch_k2<WM_, WN_, MI, NI, CONV, EPI, true>(g, batch, st);
     } else {
         if (g.K2) {
@@ -473,6 +481,18 @@ static int pp_launch(GemmArgs& g, int batch, hipStream_t st) {
         return conv ? pp_launch_k<WM_, WN_, MI, NI, true, 10>(g, batch, st) : pp_launch_k<WM_, WN_, MI, NI, false, 10>(g, batch, st);
     const bool lean = g.split_k == 1 && !g.out_f32 && !g.trans_out && g.bias_lds && (g.ldc & 7) == 0 &&
                       (!g.bias2 || g.ln_stats || g.rows_per_batch % BM == 0);
+    if (g.gn_part_out) {
+        // GroupNorm partial sums of the output: a tile that spans the row (N == BN == 320) and lies in one sample
+        if constexpr (BN == 320) {
+            if (lean && g.act == FD_ACT_NONE && !g.ln_stats && !g.ln_stats_out && g.N == BN && g.rows_per_batch % BM == 0 && !g.phase && batch == 1 &&
+                (!g.res || (g.ldr & 3) == 0)) {
+                if (g.res) return conv ? pp_launch_k<WM_, WN_, MI, NI, true, 12>(g, batch, st) : pp_launch_k<WM_, WN_, MI, NI, false, 12>(g, batch, st);
+                return conv ? pp_launch_k<WM_, WN_, MI, NI, true, 11>(g, batch, st) : pp_launch_k<WM_, WN_, MI, NI, false, 11>(g, batch, st);
+            }
+        }
+        fd_set_error("fd_gemm_f16: gn_part_out on a ping-pong tile needs the lean epilogue of a 320-wide tile inside one sample");
+        return FD_ESHAPE;
+    }
     if (g.ln_stats_out) {
         if (lean && !conv && (WN_ == 2 || g.N == BN) && g.act == FD_ACT_NONE && !g.ln_stats && !g.bias2) {
             if (g.res && (g.ldr & 3) == 0) return pp_launch_k<WM_, WN_, MI, NI, false, 9>(g, batch, st);

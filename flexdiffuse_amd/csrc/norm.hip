@@ -389,6 +389,24 @@ extern "C" int fd_groupnorm_fold_linear_f16(const void* x, int ldx, float* ws, i
     return FD_OK;
 }
 
+extern "C" int fd_groupnorm_fold_linear_parts_f16(const float* parts, int chunks, int B, int HW, int C, int G, float eps,
+                                                  const void* wg, const float* biasf, int N, void* w_out, float* bias_out, void* stream) {
+    FD_PLAN(fd_groupnorm_fold_linear_parts_f16(parts, chunks, B, HW, C, G, eps, wg, biasf, N, w_out, bias_out, fd_s_));
+    FD_CHECK_ARG(parts && wg && biasf && w_out && bias_out, FD_EINVAL, "fd_groupnorm_fold_linear_parts_f16: null pointer");
+    FD_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && N > 0 && chunks > 0, FD_EINVAL, "fd_groupnorm_fold_linear_parts_f16: bad dims");
+    FD_CHECK_ARG(C % 8 == 0 && C % G == 0 && G <= 64 && ((uintptr_t)wg | (uintptr_t)w_out) % 16 == 0, FD_ESHAPE,
+                 "fd_groupnorm_fold_linear_parts_f16: C=%d must be a multiple of 8 and of G=%d (G <= 64); wg / w_out 16-byte aligned", C, G);
+    const size_t lds2 = (size_t)GNF_ROWS * C * sizeof(half_t);
+    FD_CHECK_ARG(lds2 <= 48 * 1024, FD_ESHAPE, "fd_groupnorm_fold_linear_parts_f16: C=%d too wide for the fold kernel's weight tile", C);
+    hipStream_t st = (hipStream_t)stream;
+    fd_prof_begin(FD_FAMILY_GROUPNORM, st, 0.0, -1.0, fd_tag(12u, B, HW, C, N));   // no pass over the activation at all
+    hipLaunchKernelGGL(k_gn_fold_linear, dim3(fd_cdiv(N, GNF_ROWS), B), dim3(256), lds2, st, parts, chunks, HW, C, G, eps,
+                       (const half_t*)wg, biasf, N, (half_t*)w_out, bias_out);
+    fd_prof_end(FD_FAMILY_GROUPNORM, st);
+    FD_CHECK_LAUNCH("k_gn_fold_linear");
+    return FD_OK;
+}
+
 extern "C" int64_t fd_groupnorm_workspace_floats(int B, int G) {
     return (int64_t)B * GN_MAX_CHUNKS * G * 2;
 }
@@ -447,6 +465,37 @@ extern "C" int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const f
                        (half_t*)y, (const float*)ws, gamma, beta, HW, C, G, nchunk, PL, ppc, eps, silu, ldx);
     fd_prof_end(FD_FAMILY_GROUPNORM, st);
     FD_CHECK_LAUNCH("k_gn_stats/k_gn_apply");
+    return FD_OK;
+}
+
+// The apply pass alone: the statistics come as partial sums written by the PRODUCER of x (fd_gemm_desc.gn_part_out: the lean
+// epilogue of the convolution that wrote x), [B][chunks][G][2] -- the layout k_gn_stats writes.
+extern "C" int fd_groupnorm_apply_parts_f16(const void* x, int ldx, void* y, const float* gamma, const float* beta, const float* parts,
+                                            int chunks, int B, int HW, int C, int G, float eps, int silu, void* stream) {
+    FD_PLAN(fd_groupnorm_apply_parts_f16(x, ldx, y, gamma, beta, parts, chunks, B, HW, C, G, eps, silu, fd_s_));
+    FD_CHECK_ARG(x && y && gamma && beta && parts, FD_EINVAL, "fd_groupnorm_apply_parts_f16: null pointer");
+    FD_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && chunks > 0, FD_EINVAL, "fd_groupnorm_apply_parts_f16: bad dims");
+    FD_CHECK_ARG(ldx >= C && ldx % 8 == 0 && (uintptr_t)x % 16 == 0 && C % 8 == 0 && C % G == 0 && G <= 64 && C / 8 <= 1024, FD_ESHAPE,
+                 "fd_groupnorm_apply_parts_f16: ldx=%d >= C=%d, both multiples of 8, C a multiple of G=%d (G <= 64), x 16-byte aligned", ldx, C, G);
+    FD_CHECK_ARG((long long)B * HW * ldx < 0x7fffffffLL, FD_ESHAPE, "fd_groupnorm_apply_parts_f16: tensor too large");
+    hipStream_t st = (hipStream_t)stream;
+    const int c8 = C / 8;
+    int PL = 512 / c8;
+    if (PL < 1) PL = 1;
+    if (PL > HW) PL = HW;
+    const int threads = ((c8 * PL + 63) / 64) * 64;
+    int nchunk = 256 / B;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
+    int ppc = fd_cdiv(HW, nchunk);
+    if (ppc < PL) ppc = PL;
+    nchunk = fd_cdiv(HW, ppc);
+    const size_t lds2 = (size_t)2 * threads * sizeof(double) + (size_t)2 * G * sizeof(float);
+    fd_prof_begin(FD_FAMILY_GROUPNORM, st, (double)B * HW * C * 4.0, -1.0, fd_tag(13u, B, HW, C, ldx));
+    hipLaunchKernelGGL(k_gn_apply, dim3(nchunk, B), dim3(threads), lds2, st, (const half_t*)x, (half_t*)y, parts, gamma, beta, HW, C, G,
+                       chunks, PL, ppc, eps, silu, ldx);
+    fd_prof_end(FD_FAMILY_GROUPNORM, st);
+    FD_CHECK_LAUNCH("k_gn_apply");
     return FD_OK;
 }
 

@@ -49,6 +49,9 @@ _SIGNATURES = {
     'fd_gemm_can_emit_row_stats': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'fd_gemm_plan': (c_int, [c_void_p, c_void_p, c_void_p]),
     'fd_gemm_can_fuse_groupnorm': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'fd_gemm_gn_parts_chunks': (c_int, [P]),
+    'fd_groupnorm_apply_parts_f16': (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    'fd_groupnorm_fold_linear_parts_f16': (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_float, P, P, c_int, P, P, P]),
     'fd_attention_f16': (c_int, [P, P]),
     'fd_xattn_image_bytes': (c_int64, [c_int, c_int]),
     'fd_xattn_pack_kv_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, P]),

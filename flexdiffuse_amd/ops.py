@@ -35,7 +35,8 @@ class fd_gemm_desc(ctypes.Structure):
                 ('ln_stats_out', c_void_p), ('ln_eps', c_float), ('A2', c_void_p), ('lda2', c_int32), ('K2', c_int32),
                 ('batch_stride_bias', c_int64),
                 ('gn_out', c_void_p), ('gn_gamma', c_void_p), ('gn_beta', c_void_p),
-                ('gn_groups', c_int32), ('gn_silu', c_int32), ('gn_eps', c_float), ('gn_skip_c', c_int32)]
+                ('gn_groups', c_int32), ('gn_silu', c_int32), ('gn_eps', c_float), ('gn_skip_c', c_int32),
+                ('gn_part_out', c_void_p)]
 
 
 class fd_attention_desc(ctypes.Structure):
@@ -297,9 +298,11 @@ def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[to
          out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0,
          use_bias: bool = True, ln_stats: Optional[torch.Tensor] = None,
          ln_stats_out: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-         a2: Optional[torch.Tensor] = None) -> torch.Tensor:
+         a2: Optional[torch.Tensor] = None, gn_parts: int = 0):
     '''a [M][K] fp16 @ w[N][K]^T with fused epilogue -> [M][N] (GEGLU: [M][N/2]).  `a2` [M][K2]: a second operand
-    accumulated by the same K loop against w[:, K:K+K2] (fd_gemm_desc.A2 / K2; `w` holds K + K2 columns).'''
+    accumulated by the same K loop against w[:, K:K+K2] (fd_gemm_desc.A2 / K2; `w` holds K + K2 columns).
+    `gn_parts` = G > 0 (needs rows_per_sample): -> (out, GNParts or None): the GroupNorm partial sums of the output over G groups
+    from the launch's own epilogue where the library can (fd_gemm_desc.gn_part_out), for the GroupNorm that reads `out` next.'''
     M, K = a.shape
     K2 = 0 if a2 is None else a2.shape[1]
     assert a.dtype == torch.float16 and a.stride(1) == 1 and K + K2 == w.K, (a.shape, K2, w.K)
@@ -328,6 +331,10 @@ def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[to
         assert ln_stats_out.shape[-2:] == (M, 2) and ln_stats_out.dtype == torch.float32 and ln_stats_out.is_contiguous()
         d.ln_stats_out, d.ln_eps = ln_stats_out.data_ptr(), ln_eps
     _sched(d, a.device)
+    if gn_parts:
+        parts = _gn_parts_request(d, M // rows_per_sample, gn_parts, a) if rows_per_sample > 0 and M % rows_per_sample == 0 else None
+        hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+        return out, parts
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     return out
 
@@ -383,17 +390,46 @@ class GNSpec:
     silu: bool
 
 
+@dataclass
+class GNParts:
+    '''GroupNorm partial sums [B][chunks][G][2] written by the producer of a tensor (fd_gemm_desc.gn_part_out).'''
+    t: torch.Tensor
+    chunks: int
+    G: int
+
+
+GN_PARTS = os.environ.get('FD_GN_PARTS', '1') != '0'     # GroupNorm statistics from the producing launch's epilogue (A/B: 0 = statistics pass)
+
+
+def _gn_parts_request(d: 'fd_gemm_desc', B: int, G: int, like: torch.Tensor) -> Optional[GNParts]:
+    '''Asks the library whether the launch described by `d` can write the GroupNorm partial sums of its output over G groups;
+    if so allocates them, sets d.gn_part_out / d.gn_groups and returns the GNParts the consumer takes.'''
+    if not GN_PARTS or d.act != ACT_NONE or d.out_f32:
+        return None
+    d.gn_groups = G
+    chunks = hip.lib().fd_gemm_gn_parts_chunks(ctypes.byref(d))
+    if chunks <= 0:
+        return None
+    t = _empty((B, chunks, G, 2), torch.float32, like)
+    d.gn_part_out = t.data_ptr()
+    return GNParts(t, chunks, G)
+
+
 def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), up: bool = False,
            out_hw: Optional[Tuple[int, int]] = None, act: int = ACT_NONE,
            residual: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None,
            ld_bias2: int = 0, out_f32: bool = False, out: Optional[torch.Tensor] = None,
-           a2: Optional[torch.Tensor] = None, gn: Optional[GNSpec] = None, keep: bool = True):
+           a2: Optional[torch.Tensor] = None, gn: Optional[GNSpec] = None, keep: bool = True, gn_parts: int = 0):
     '''NHWC conv (kh x kw) as implicit GEMM; `up` fuses a nearest-2x upsample of the input.  `a2` [M][Cx]
     (row stride free): the rows of the 1x1 shortcut appended to `w` by prep_conv_shortcut.
     `gn`: also return GroupNorm(+SiLU) of the output -> (Act or None, Act): where the library splits the convolution over K
     (the 16x16 / 8x8 UNet levels) the pass that sums the partial slabs normalises them too (fd_gemm_desc.gn_out: one launch
     less; with keep=False the un-normalised output is never written and the first element is None); everywhere else the
-    convolution is followed by the ordinary groupnorm launch.  Same bits either way.'''
+    convolution is followed by the groupnorm launch -- at the 64x64 level (one 320-wide tile spans the row) without its statistics
+    pass: the convolution's epilogue writes the partial sums (fd_gemm_desc.gn_part_out).  The fused form gives the bits of the
+    separate launches; the partial-sum form differs from them in the summation order of the statistics only.
+    `gn_parts` = G > 0 (without `gn`): -> (Act, GNParts or None): just the partial sums over G groups next to the output, for a
+    consumer that needs statistics only (gn_fold_linear) or normalises later.'''
     assert x.C == w.cin, (x.C, w.cin)
     Hv, Wv = (x.H * 2, x.W * 2) if up else (x.H, x.W)
     if out_hw is None:
@@ -448,14 +484,19 @@ def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), 
         _last_conv_gn_fused = bool(fuse)      # (read by the tests: which form the last conv2d(..., gn=) took)
         gn_fused_launches += int(bool(fuse))
         if not fuse:
+            parts = _gn_parts_request(d, x.B, gn.G, x.t)
             hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
             res = Act(out, x.B, Ho, Wo)
-            return res, groupnorm(res, gn.gamma, gn.beta, gn.G, gn.eps, gn.silu)
+            return res, groupnorm(res, gn.gamma, gn.beta, gn.G, gn.eps, gn.silu, parts=parts)
         y = _empty((M, w.cout), torch.float16, x.t)
         d.gn_out, d.gn_gamma, d.gn_beta = y.data_ptr(), gn.gamma.data_ptr(), gn.beta.data_ptr()
         d.gn_groups, d.gn_silu, d.gn_eps, d.gn_skip_c = gn.G, int(gn.silu), gn.eps, int(not keep)
         hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
         return (Act(out, x.B, Ho, Wo) if keep else None), Act(y, x.B, Ho, Wo)
+    if gn_parts:
+        parts = _gn_parts_request(d, x.B, gn_parts, x.t)
+        hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+        return Act(out, x.B, Ho, Wo), parts
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     return Act(out, x.B, Ho, Wo)
 
@@ -566,10 +607,16 @@ def _gn_workspace(B: int, G: int, dev) -> torch.Tensor:
 
 
 def groupnorm(x: Act, gamma: torch.Tensor, beta: torch.Tensor, G: int, eps: float,
-              silu: bool) -> Act:
+              silu: bool, parts: Optional['GNParts'] = None) -> Act:
+    '''`parts`: the partial sums the producer of x wrote (conv2d(..., gn_parts=) / gn=): only the apply pass runs.'''
     # x may be a column slice of a wider matrix (a skip tensor living in its concat buffer)
     assert x.t.stride(1) == 1
     out = _empty(tuple(x.t.shape), torch.float16, x.t)
+    if parts is not None:
+        assert parts.G == G and parts.t.shape == (x.B, parts.chunks, G, 2)
+        hip.call('fd_groupnorm_apply_parts_f16', x.t.data_ptr(), x.t.stride(0), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                 parts.t.data_ptr(), parts.chunks, x.B, x.HW, x.C, G, eps, int(silu), hip.stream())
+        return Act(out, x.B, x.H, x.W)
     ws = _gn_workspace(x.B, G, x.t.device)
     hip.call('fd_groupnorm_nhwc_ld_f16', x.t.data_ptr(), x.t.stride(0), out.data_ptr(), gamma.data_ptr(),
              beta.data_ptr(), ws.data_ptr(), x.B, x.HW, x.C, G, eps, int(silu), hip.stream())
@@ -611,11 +658,17 @@ def gn_fold_supported(B: int, HW: int, N: int, C: Optional[int] = None, G: int =
             and C <= GN_FOLD_MAX_C and G <= GN_FOLD_MAX_G)
 
 
-def gn_fold_linear(x: Act, gf: GNFold) -> Tuple[torch.Tensor, torch.Tensor]:
-    '''One statistics pass over x, then sample b's scaled weights [B][N][C] fp16 and bias [B][N] fp32.'''
+def gn_fold_linear(x: Act, gf: GNFold, parts: Optional['GNParts'] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    '''One statistics pass over x (none when the producer of x wrote `parts`), then sample b's scaled weights [B][N][C] fp16 and
+    bias [B][N] fp32.'''
     assert x.t.stride(1) == 1 and x.C == gf.C
     wb = _empty((x.B, gf.N, gf.C), torch.float16, x.t)
     bb = _empty((x.B, gf.N), torch.float32, x.t)
+    if parts is not None:
+        assert parts.G == gf.G and parts.t.shape == (x.B, parts.chunks, gf.G, 2)
+        hip.call('fd_groupnorm_fold_linear_parts_f16', parts.t.data_ptr(), parts.chunks, x.B, x.HW, gf.C, gf.G, gf.eps,
+                 gf.wg.data_ptr(), gf.biasf.data_ptr(), gf.N, wb.data_ptr(), bb.data_ptr(), hip.stream())
+        return wb, bb
     ws = _gn_workspace(x.B, gf.G, x.t.device)
     hip.call('fd_groupnorm_fold_linear_f16', x.t.data_ptr(), x.t.stride(0), ws.data_ptr(), x.B, x.HW, gf.C, gf.G, gf.eps,
              gf.wg.data_ptr(), gf.biasf.data_ptr(), gf.N, wb.data_ptr(), bb.data_ptr(), hip.stream())

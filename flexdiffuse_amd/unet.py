@@ -267,19 +267,25 @@ class UNet2DConditionModel():
         '''norm1 + SiLU of ResBlock `r` as a spec its input's PRODUCER can take (ops.conv2d(..., gn=)).'''
         return None if r is None else ops.GNSpec(r.n1g, r.n1b, self.G, 1e-5, True)
 
-    def _attn_gn(self, a: Optional[_Attn], x: Act) -> Optional[ops.GNSpec]:
-        '''The transformer block's input GroupNorm as a producer-side spec -- only where the block reads a normalised tensor
-        (where the GroupNorm is folded into proj_in, ops.gn_fold_supported, there is nothing to produce).'''
-        if a is None or ops.gn_fold_supported(x.B, x.HW, a.C, a.C, self.G):
+    def _attn_gn(self, a: Optional[_Attn], x: Act):
+        '''What the producer of a transformer block's input can prepare for the block's GroupNorm: the normalised tensor (a GNSpec
+        for ops.conv2d(..., gn=)) where the block reads one, or -- where the GroupNorm is folded into proj_in
+        (ops.gn_fold_supported: only its statistics are needed) -- the group count, for the producer's partial sums (gn_parts=).'''
+        if a is None:
             return None
+        if ops.gn_fold_supported(x.B, x.HW, a.C, a.C, self.G):
+            return self.G
         return ops.GNSpec(a.ng, a.nb, self.G, 1e-6, False)
 
     def _res(self, r: _Res, x: Act, temb: torch.Tensor, out: Optional[torch.Tensor] = None, xn: Optional[Act] = None,
-             next_gn: Optional[ops.GNSpec] = None):
-        '''ResBlock -> (output, GroupNorm `next_gn` of the output or None).  `xn`: norm1 + SiLU of `x` when the producer of x
+             next_gn=None):
+        '''ResBlock -> (output, GroupNorm `next_gn` of the output / its partial sums (next_gn an int: the group count) / None).  `xn`: norm1 + SiLU of `x` when the producer of x
         already made it (the split-K finish of the previous convolution); `next_gn`: the normalisation the consumer of this
         block's output starts with, handed to conv2 the same way.'''
-        h = xn if xn is not None else ops.groupnorm(x, r.n1g, r.n1b, self.G, 1e-5, True)
+        if isinstance(xn, Act):
+            h = xn
+        else:       # (xn an ops.GNParts: the statistics come from x's producer, only the apply pass runs)
+            h = ops.groupnorm(x, r.n1g, r.n1b, self.G, 1e-5, True, parts=xn)
         # conv1 feeds nothing but norm2 + SiLU: where the convolution is split over K (16x16 / 8x8 levels) the finish pass of
         # the split normalises the tile it has just summed (fd_gemm_desc.gn_out) and conv1's own output is never written
         _, h = ops.conv2d(h, r.conv1, bias2=temb[:, r.temb_off:r.temb_off + r.cout], ld_bias2=self.temb_total,
@@ -287,17 +293,21 @@ class UNet2DConditionModel():
         kw = dict(a2=x.t) if r.sc_fused else dict(residual=x.t if r.short is None else ops.gemm(x.t, r.short))
         if next_gn is None:
             return ops.conv2d(h, r.conv2, out=out, **kw), None
+        if isinstance(next_gn, int):
+            return ops.conv2d(h, r.conv2, out=out, gn_parts=next_gn, **kw)
         return ops.conv2d(h, r.conv2, out=out, gn=next_gn, keep=True, **kw)
 
-    def _attn(self, a: _Attn, x: Act, rep: int = 1, out: Optional[torch.Tensor] = None, xn: Optional[Act] = None) -> Act:
+    def _attn(self, a: _Attn, x: Act, rep: int = 1, out: Optional[torch.Tensor] = None, xn=None, next_parts: int = 0):
         '''Transformer block.  rep > 1: `x` holds B samples that are shared by `rep` branches of
         the cached context (CFG: [uncond]*B + cond on the same latents).  Everything up to the
         cross-attention query is branch-independent and computed once; the output has rep*B
-        samples.  `xn`: the block's input GroupNorm of `x` when the producer of x already made it (_attn_gn).'''
+        samples.  `xn`: what the producer of x prepared for the block's input GroupNorm (_attn_gn): the normalised tensor, or the
+        partial sums of the statistics (ops.GNParts) where the GroupNorm is folded into proj_in.  `next_parts` = G > 0: the block's
+        output is read next by a GroupNorm over G groups -> (output, ops.GNParts or None): the last GEMM's epilogue writes the partial sums.'''
         B, HW, C = x.B, x.HW, a.C
         d = C // a.heads
         gn_fold = ops.gn_fold_supported(B, HW, C, C, self.G)
-        h = None if gn_fold else (xn if xn is not None else ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False))
+        h = None if gn_fold else (xn if isinstance(xn, Act) else ops.groupnorm(x, a.ng, a.nb, self.G, 1e-6, False))
         # LayerNorm fold: the GEMM that PRODUCES a LayerNorm input also writes its row statistics where one
         # tile spans the row (C == 320: the 64x64 level); elsewhere one read-only statistics pass
         # (C == 320: finished pairs; wider rows: raw partial sums per 160-column tile + a tiny finalise launch)
@@ -317,7 +327,7 @@ class UNet2DConditionModel():
                 return ops.ln_row_stats(hh)
             return st if st.dim() == 2 else ops.ln_finalize_stats(st, C)
         if gn_fold:
-            wb, bb = ops.gn_fold_linear(x, a.gnf)
+            wb, bb = ops.gn_fold_linear(x, a.gnf, parts=xn if isinstance(xn, ops.GNParts) else None)
             st = mkst(HW, B)
             h = ops.gemm_per_sample(x.t, wb, bb, B, HW, ln_stats_out=st)
         else:
@@ -362,9 +372,13 @@ class UNet2DConditionModel():
         else:
             f = ops.gemm(ops.layernorm(h, *a.ln[2]), a.ff1, act=ops.ACT_GEGLU)
         if a.ffp is not None:
+            if next_parts:
+                o, parts = ops.gemm(f, a.ffp, a2=h, residual=xt, out=out, rows_per_sample=HW, gn_parts=next_parts)
+                return Act(o, B, x.H, x.W), parts
             return Act(ops.gemm(f, a.ffp, a2=h, residual=xt, out=out), B, x.H, x.W)
         h = ops.gemm(f, a.ff2, residual=h)
-        return Act(ops.gemm(h, a.proj_out, residual=xt, out=out), B, x.H, x.W)
+        res = Act(ops.gemm(h, a.proj_out, residual=xt, out=out), B, x.H, x.W)
+        return (res, None) if next_parts else res
 
     # ---- forward ----------------------------------------------------------------------------
     def time_bias(self, timestep, B: int) -> torch.Tensor:
@@ -447,8 +461,12 @@ class UNet2DConditionModel():
                 nres += 1
                 if a is not None:
                     h, hn = self._res(r, h, temb[:h.B], xn=pend, next_gn=self._attn_gn(a, h))
-                    pend = None
-                    h = self._attn(a, h, fan, out=view, xn=hn)
+                    # (the next ResBlock of this level reads the transformer block's output directly: its norm1 statistics come
+                    # from the block's last GEMM where that launch can write them -- the 64x64 level)
+                    if r is not blk['res'][-1]:
+                        h, pend = self._attn(a, h, fan, out=view, xn=hn, next_parts=self.G)
+                    else:
+                        h, pend = self._attn(a, h, fan, out=view, xn=hn), None
                 elif fan > 1:
                     h, pend = self._res(r, h, temb[:h.B], xn=pend)
                     if view is None:
@@ -473,6 +491,7 @@ class UNet2DConditionModel():
         h, hn = self._res(self.mid_res0, h, temb, xn=pend, next_gn=self._attn_gn(self.mid_attn, h))
         h = self._attn(self.mid_attn, h, xn=hn)
         h, _ = self._res(self.mid_res1, h, temb, out=left(h.B * h.HW, self.mid_res1.cout))
+        out_parts = None
         for blk in self.up:
             n = len(blk['res'])
             for j, (r, a) in enumerate(zip(blk['res'], blk['attn'])):
@@ -487,7 +506,10 @@ class UNet2DConditionModel():
                 dst = None if (last and blk['up'] is not None) else left(h.B * h.HW, r.cout)
                 if a is not None:
                     h, hn = self._res(r, h, temb, next_gn=self._attn_gn(a, h))
-                    h = self._attn(a, h, out=dst, xn=hn)
+                    if last and blk['up'] is None:      # the very last block: conv_norm_out reads its output
+                        h, out_parts = self._attn(a, h, out=dst, xn=hn, next_parts=self.G)
+                    else:
+                        h = self._attn(a, h, out=dst, xn=hn)
                 else:
                     h, _ = self._res(r, h, temb, out=dst)
             if blk['up'] is not None:
@@ -496,7 +518,7 @@ class UNet2DConditionModel():
                     h = ops.conv2d_up_phases(h, blk['up_ph'], out=dst)
                 else:
                     h = ops.conv2d(h, blk['up'], up=True, out=dst)
-        h = ops.groupnorm(h, self.out_g, self.out_b, self.G, 1e-5, True)
+        h = ops.groupnorm(h, self.out_g, self.out_b, self.G, 1e-5, True, parts=out_parts)
         return ops.conv2d(h, self.conv_out, out_f32=True).t
 
     def forward(self, sample, timestep, encoder_hidden_states) -> UNetOutput:

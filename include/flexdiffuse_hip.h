@@ -237,6 +237,15 @@ typedef struct fd_gemm_desc {
     int32_t gn_groups, gn_silu;
     float gn_eps;
     int32_t gn_skip_c;
+    /* (ABI 11) GroupNorm PARTIAL SUMS of the output from the epilogue of the producing launch: gn_part_out
+     * [M / rows_per_sample][chunks][gn_groups][2] fp32 = (sum, sum of squares) of the fp16-rounded outputs of each (sample, row
+     * chunk, group) -- the layout fd_groupnorm_apply_parts_f16 / fd_groupnorm_fold_linear_parts_f16 consume, `chunks` =
+     * fd_gemm_gn_parts_chunks(desc).  At the 64x64 level of `unet(...)` (reference pipeline/guide.py:56-58) the GroupNorms behind a
+     * convolution (norm2 behind conv1, the transformer's input norm behind conv2) then need no statistics pass over the tensor the
+     * convolution has just written.  Honoured where one tile spans the row and lies in one sample (N == 320, the 256x320 / 128x320
+     * tiles, lean epilogue, act NONE, batch 1, no split-K); FD_ESHAPE otherwise -- ask fd_gemm_gn_parts_chunks first.  Uses gn_groups.
+     * NULL = off. */
+    float* gn_part_out;
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);
@@ -253,6 +262,9 @@ int fd_gemm_plan(const fd_gemm_desc* d, int* tile, int* split_k);
  * fd_gemm_desc.gn_out with `groups` groups (the slab of one sample x a few groups fits the finish kernel's registers); 0: run
  * fd_groupnorm_nhwc_f16 on the output instead.  Host logic only. */
 int fd_gemm_can_fuse_groupnorm(int M, int N, int rows_per_sample, int groups, int split_k);
+/* (ABI 11) Row chunks per sample of fd_gemm_desc.gn_part_out for `d` (with d->gn_groups set): > 0 when fd_gemm_f16 will honour it with the
+ * tile the rule picks, 0: run the statistics pass on the output instead.  Host logic only. */
+int fd_gemm_gn_parts_chunks(const fd_gemm_desc* d);
 
 /* Flash attention forward (scores never leave registers).  Q [B][n_q][ldq], K [B][n_k][ldk]
  * with head h at column h*head_dim; Vt [B][heads*head_dim][ldvt] is V transposed (keys
@@ -319,6 +331,10 @@ int fd_groupnorm_nhwc_f16(const void* x, void* y, const float* gamma, const floa
 int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const float* gamma, const float* beta,
                              float* ws, int B, int HW, int C, int G, float eps, int silu,
                              void* stream);
+/* (ABI 11) The apply pass alone, from partial sums parts [B][chunks][G][2] that the PRODUCER of x wrote (fd_gemm_desc.gn_part_out):
+ * y = GroupNorm(x)(+SiLU) without the statistics pass over x. */
+int fd_groupnorm_apply_parts_f16(const void* x, int ldx, void* y, const float* gamma, const float* beta, const float* parts,
+                                 int chunks, int B, int HW, int C, int G, float eps, int silu, void* stream);
 /* GroupNorm folded into the linear layer that consumes it (the transformer block's norm -> proj_in, diffusers
  * Transformer2DModel.norm / proj_in inside the `unet(...)` call of reference pipeline/guide.py:56-58):
  *   proj_in(GN(x))[m][n] = sum_c w_out[b][n][c] x[m][c] + (bias[n] + (W beta)[n] - sum_g mean_{b,g} sum_{c in g} w_out[b][n][c]),
@@ -331,6 +347,9 @@ int fd_groupnorm_nhwc_ld_f16(const void* x, int ldx, void* y, const float* gamma
 int fd_groupnorm_fold_linear_f16(const void* x, int ldx, float* ws, int B, int HW, int C, int G, float eps,
                                  const void* wg, const float* biasf, int N,
                                  void* w_out, float* bias_out, void* stream);
+/* (ABI 11) The same from the producer's partial sums (fd_gemm_desc.gn_part_out), without reading x at all. */
+int fd_groupnorm_fold_linear_parts_f16(const float* parts, int chunks, int B, int HW, int C, int G, float eps,
+                                       const void* wg, const float* biasf, int N, void* w_out, float* bias_out, void* stream);
 /* LayerNorm over the last dim of fp16 x [rows][ldx] -> fp16 (or fp32) y [rows][ldy]. */
 int fd_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int rows,
                      int C, int ldx, int ldy, float eps, int out_f32, void* stream);

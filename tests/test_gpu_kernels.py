@@ -1003,3 +1003,92 @@ def test_fused_cross_attention_race_screen(dev, B, HW, rep, d):
         bad += (out != ref).sum()
     torch.cuda.synchronize()
     assert int(bad) == 0, int(bad)
+
+
+@pytest.mark.parametrize('B,H,Cx,res', [(16, 64, 0, False), (8, 64, 0, False), (16, 64, 0, True), (16, 64, 640, False), (16, 64, 960, False)])
+def test_groupnorm_partial_sums_from_the_producing_convolution(dev, B, H, Cx, res):
+    '''fd_gemm_desc.gn_part_out: the lean epilogue of a 320-wide row-spanning tile (ping-pong 256x320 / 128x320, the 2-barrier 256x320
+    tile of the convolutions with an appended shortcut) writes per-(sample, row chunk, group) partial (sum, sum of squares) of its
+    fp16-rounded output, so the GroupNorm behind it -- a ResBlock's norm2 behind conv1, the transformer block's folded input norm
+    behind conv2 -- runs without its statistics pass.  Checks: the partial sums against torch on the stored output; the apply pass
+    from them against torch GroupNorm + SiLU and against the two-pass kernel (the statistics differ in summation order only: a few
+    fp16 ulps); the folded per-sample weights against the statistics-pass form; 20 repeats bit for bit.'''
+    from flexdiffuse_amd import ops
+    C, G, eps = 320, 32, 1e-5
+    g = torch.Generator().manual_seed(B * H + Cx + int(res))
+    M = B * H * H
+    hx = (torch.randn((M, C), generator=g) * 0.7 + 0.2).half().to(dev)
+    w = torch.randn((C, C, 3, 3), generator=g) * (9 * C) ** -0.5 * 1.5
+    b = torch.randn(C, generator=g) * 0.3
+    temb = (torch.randn((B, C), generator=g) * 0.5).to(dev)
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.3 * torch.randn(C, generator=g)).to(dev)
+    hd = ops.Act(hx, B, H, H)
+    kw = {}
+    if Cx:
+        cw = ops.prep_conv_shortcut(w, b, torch.randn((C, Cx), generator=g) * Cx ** -0.5, None, dev)
+        kw['a2'] = (torch.randn((M, Cx), generator=g) * 0.7).half().to(dev)
+    else:
+        cw = ops.prep_conv(w, b, dev)
+        kw.update(bias2=temb, ld_bias2=C)
+    if res:
+        kw['residual'] = (torch.randn((M, C), generator=g) * 2.0 + 1.0).half().to(dev)     # group means far from zero
+    out, parts = ops.conv2d(hd, cw, gn_parts=G, **kw)
+    assert parts is not None and parts.t.shape == (B, parts.chunks, G, 2) and parts.chunks in (16, 32), 'the rule no longer emits partial sums here'
+    plain = ops.conv2d(hd, cw, **kw)
+    # the output itself: the same values -- up to the last fp16 bit of a few elements in 10^5: with the statistics code next to it hipcc
+    # rounds some accumulators fp32 -> fp16 in one step (v_fma_mix*_f16) where the plain epilogue rounds fma -> fp32 -> fp16
+    dd = (out.t.float() - plain.t.float()).abs()
+    assert float((dd > 0).float().mean()) < 1e-3 and float((dd / plain.t.float().abs().clamp_min(1e-3)).max()) <= 2.0 ** -9
+    o32 = out.t.float().view(B, parts.chunks, H * H // parts.chunks, G, C // G)
+    want_s, want_q = o32.sum(dim=(2, 4)), (o32 * o32).sum(dim=(2, 4))
+    assert float((parts.t[..., 0] - want_s).abs().max()) <= 2e-4 * float(want_s.abs().max()) + 1e-2
+    assert float((parts.t[..., 1] - want_q).abs().max()) <= 2e-4 * float(want_q.abs().max())
+    # apply from the partial sums
+    y = ops.groupnorm(out, gamma, beta, G, eps, True, parts=parts)
+    y2 = ops.groupnorm(out, gamma, beta, G, eps, True)
+    o4 = out.t.float().view(B, H * H, C).permute(0, 2, 1).reshape(B, C, H, H)
+    want = F.silu(F.group_norm(o4, G, gamma, beta, eps))
+    close(y.t.float().view(B, H * H, C).permute(0, 2, 1).reshape(B, C, H, H), want, rtol=4e-3, atol=4e-3)
+    d = (y.t.float() - y2.t.float()).abs()
+    assert float(d.max()) <= 4e-3 * float(y2.t.float().abs().max()) and float((d > 0).float().mean()) < 0.2
+    # conv2d(..., gn=) takes the same route when the launch is not split over K
+    _, y3 = ops.conv2d(hd, cw, gn=ops.GNSpec(gamma, beta, G, eps, True), **kw)
+    assert torch.equal(y3.t, y.t) and ops._last_conv_gn_fused is False
+    # the folded form: per-sample weights / bias from the partial sums vs from the statistics pass
+    wl = torch.randn((C, C), generator=g) * C ** -0.5
+    gf = ops.prep_gn_fold(wl, torch.randn(C, generator=g) * 0.1, gamma.cpu(), beta.cpu(), G, 1e-6, dev)
+    wb, bb = ops.gn_fold_linear(out, gf, parts=parts)
+    wb2, bb2 = ops.gn_fold_linear(out, gf)
+    assert float((wb.float() - wb2.float()).abs().max()) <= 2e-3 * float(wb2.float().abs().max())
+    assert float((bb - bb2).abs().max()) <= 2e-3 * max(1.0, float(bb2.abs().max()))
+    # repeats bit for bit
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(20):
+        _, p2 = ops.conv2d(hd, cw, gn_parts=G, **kw)
+        bad += (p2.t != parts.t).sum()
+    assert int(bad) == 0
+
+
+def test_groupnorm_partial_sums_are_refused_where_no_tile_spans_the_row(dev):
+    '''gn_part_out on a launch whose tile does not span the row / whose launch is split answers FD_ESHAPE; fd_gemm_gn_parts_chunks says
+    so beforehand (the Python front asks it and falls back to the statistics pass).'''
+    import ctypes
+    from flexdiffuse_amd import hip, ops
+    g = torch.Generator().manual_seed(9)
+    for (B, H, C) in ((16, 16, 1280), (16, 32, 640)):
+        hd = ops.Act((torch.randn((B * H * H, C), generator=g) * 0.5).half().to(dev), B, H, H)
+        cw = ops.prep_conv(torch.randn((C, C, 3, 3), generator=g) * 0.01, torch.zeros(C), dev)
+        out, parts = ops.conv2d(hd, cw, gn_parts=32)
+        assert parts is None
+        d = ops.fd_gemm_desc()
+        d.A, d.W, d.C, d.bias = hd.t.data_ptr(), cw.w.data_ptr(), out.t.data_ptr(), cw.bias.data_ptr()
+        d.M, d.N, d.K, d.ldw, d.ldc, d.lda = B * H * H, C, cw.kpad, cw.w.stride(0), C, C
+        d.rows_per_sample, d.alpha, d.batch = H * H, 1.0, 1
+        d.conv, d.in_h, d.in_w, d.in_c, d.out_h, d.out_w, d.kh, d.kw, d.stride, d.pad_t, d.pad_l = 1, H, H, C, H, H, 3, 3, 1, 1, 1
+        ops._sched(d, dev)
+        d.gn_groups = 32
+        assert hip.lib().fd_gemm_gn_parts_chunks(ctypes.byref(d)) == 0
+        buf = torch.empty((B, 64, 32, 2), dtype=torch.float32, device=dev)
+        d.gn_part_out = buf.data_ptr()
+        with pytest.raises(ValueError, match='gn_part_out'):
+            hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
