@@ -1574,7 +1574,8 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
         return FD_OK;
     }
     if (g.gn_part_out)
-        FD_CHECK_ARG(gn_parts_bm(g, best_tile, best_split, batch) > 0 && (uintptr_t)g.gn_part_out % 8 == 0, FD_ESHAPE,
+        FD_CHECK_ARG(gn_parts_bm(g, best_tile, best_split, batch) > 0 && (uintptr_t)g.gn_part_out % 8 == 0 &&
+                         g.rows_per_batch / gn_parts_bm(g, best_tile, best_split, batch) == d->gn_part_chunks, FD_ESHAPE,
                      "fd_gemm_f16: gn_part_out cannot be honoured by tile %d x split %d of M=%d N=%d (rows per sample %d, %d groups); ask fd_gemm_gn_parts_chunks first",
                      best_tile, best_split, g.M, g.N, g.rows_per_batch, g.gn_groups);
     if (g.gn_out)

@@ -36,7 +36,7 @@ class fd_gemm_desc(ctypes.Structure):
                 ('batch_stride_bias', c_int64),
                 ('gn_out', c_void_p), ('gn_gamma', c_void_p), ('gn_beta', c_void_p),
                 ('gn_groups', c_int32), ('gn_silu', c_int32), ('gn_eps', c_float), ('gn_skip_c', c_int32),
-                ('gn_part_out', c_void_p)]
+                ('gn_part_out', c_void_p), ('gn_part_chunks', c_int32)]
 
 
 class fd_attention_desc(ctypes.Structure):
@@ -411,7 +411,7 @@ def _gn_parts_request(d: 'fd_gemm_desc', B: int, G: int, like: torch.Tensor) -> 
     if chunks <= 0:
         return None
     t = _empty((B, chunks, G, 2), torch.float32, like)
-    d.gn_part_out = t.data_ptr()
+    d.gn_part_out, d.gn_part_chunks = t.data_ptr(), chunks
     return GNParts(t, chunks, G)
 
 

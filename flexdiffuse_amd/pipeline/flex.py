@@ -94,6 +94,8 @@ class FlexPipeline():
         # used when use_graph is off or fell back
         self.use_plan = True
         self._plans = {}
+        # (timestep -> row, [steps][sum Cout] table) of the ResBlocks' time-embedding biases for the running request's timesteps
+        self._temb_tab = None
         # opt-in (bench.py, Runner(pause_gc=True)): keep the cyclic GC off across the denoising loop.
         # Off by default: a drop-in must not change interpreter-global state of someone else's process.
         self.pause_gc = False
@@ -155,35 +157,49 @@ class FlexPipeline():
             return self.numpy_to_pil(image)
         return image
 
+    def _temb_row(self, t) -> torch.Tensor:
+        '''[1][sum Cout] fp32 time-embedding biases of timestep t: a row of the table the running request computed for all of its
+        timesteps at once (`__call__`), or computed here for a timestep outside it.'''
+        tab = self._temb_tab
+        if tab is not None:
+            i = tab[0].get(float(t))
+            if i is not None:
+                return tab[1][i:i + 1]
+        return self.unet.time_bias(float(t), 1)
+
     def _unet_eps(self, latents: torch.Tensor, t: int, ctx: torch.Tensor, rep: int) -> torch.Tensor:
         '''UNet noise prediction (NHWC fp32) for the fused loop; graph-replayed when enabled.
-        `latents` must be the loop's persistent buffer (updated in place by the DDIM kernel).'''
+        `latents` must be the loop's persistent buffer (updated in place by the DDIM kernel).  The time embedding does not
+        depend on the latents: the replayed forward reads the ResBlocks' time biases from a persistent buffer that is refreshed
+        per step from the request's table (`_temb_row`) -- the three time-embedding GEMMs are not part of the step.'''
         # (per-launch event timing -- bench.py's roofline leg -- cannot see inside a graph: it replays the launch plan,
         # the same kernels in the same order issued by one host call)
         if (self.use_plan and not self.use_graph) or (self.use_graph and hip.prof_is_on()):
             return self._unet_eps_plan(latents, t, ctx, rep)
+        Be = latents.shape[0] * rep
         if not self.use_graph:
-            return self.unet.forward_nhwc(latents, t, ctx, rep=rep)
+            return self.unet.forward_nhwc(latents, t, ctx, rep=rep, temb=self._temb_row(t).expand(Be, -1).contiguous())
         self.unet.set_context(ctx)               # eager, in place: the graph reads these buffers
         # ctx_generation changes when the UNet had to reallocate its cached K / V^T (a call with
         # another context shape in between): a graph captured before that reads freed memory
         key = (latents.data_ptr(), tuple(latents.shape), rep, tuple(ctx.shape),
                getattr(self.unet, 'ctx_generation', 0))
         entry = self._graphs.get(key)
+        row = self._temb_row(t)
         if entry is None:
             self._graphs = {}                    # drop the previous graph (its private pool holds GBs) before capturing another
-            t_static = torch.zeros((1,), dtype=torch.float32, device=latents.device)
+            temb_static = torch.empty((Be, row.shape[1]), dtype=torch.float32, device=latents.device)
             # the first call runs eagerly (lazy one-time setup inside the kernels' launchers),
             # the second is captured
-            t_static.fill_(float(t))
-            self.unet.forward_nhwc(latents, t_static, ctx, rep=rep)
+            temb_static.copy_(row.expand_as(temb_static))
+            self.unet.forward_nhwc(latents, t, ctx, rep=rep, temb=temb_static)
             torch.cuda.synchronize()
             try:
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: only THIS thread's calls are checked against the capture -- a process-group watchdog
                 # thread (RCCL, N > 1) polling its events must not invalidate it
                 with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                    eps = self.unet.forward_nhwc(latents, t_static, ctx, rep=rep)
+                    eps = self.unet.forward_nhwc(latents, t, ctx, rep=rep, temb=temb_static)
             except Exception as ex:      # noqa: BLE001 -- capture is an optimisation: never fail the request over it
                 self.graph_fallback = f'HIP-graph capture failed ({type(ex).__name__}: {str(ex)[:200]}); running on the launch plan'
                 warnings.warn(self.graph_fallback, RuntimeWarning)
@@ -194,20 +210,16 @@ class FlexPipeline():
                 except Exception:        # noqa: BLE001
                     pass
                 return self._unet_eps_plan(latents, t, ctx, rep)
-            entry = (graph, t_static, eps, ctx)
+            entry = (graph, temb_static, eps, ctx)
             self._graphs = {key: entry}          # keep one graph (its pool holds GBs)
-        graph, t_static, eps, ctx_ref = entry
-        if ctx_ref is not ctx:
-            # a new context tensor of the same shape: K/V were re-projected in place above,
-            # nothing else in the graph depends on the tensor itself
-            pass
-        t_static.fill_(float(t))
+        graph, temb_static, eps, ctx_ref = entry
+        temb_static.copy_(row.expand_as(temb_static))
         graph.replay()
         return eps
 
     def _unet_eps_plan(self, latents: torch.Tensor, t: int, ctx: torch.Tensor, rep: int) -> torch.Tensor:
-        '''The UNet forward through its launch plan.  `latents` is the loop's persistent buffer; the
-        timestep lives in a one-element device tensor refreshed before every replay; the context's
+        '''The UNet forward through its launch plan.  `latents` is the loop's persistent buffer; the ResBlocks' time biases
+        live in a persistent buffer refreshed before every replay (`_temb_row`); the context's
         K / V^T are (re)projected eagerly, in place, before the replay.  The recording run executes
         inside a private torch memory pool that the plan entry keeps alive, so every intermediate
         address the recorded launches use stays reserved for them.'''
@@ -215,22 +227,23 @@ class FlexPipeline():
         key = (latents.data_ptr(), tuple(latents.shape), rep, tuple(ctx.shape),
                getattr(self.unet, 'ctx_generation', 0), hip.stream().value)
         entry = self._plans.get(key)
+        row = self._temb_row(t)
         if entry is None:
             self._plans = {}                     # one plan at a time (its pool holds the activations)
-            t_dev = torch.zeros((1,), dtype=torch.float32, device=latents.device)
-            t_dev.fill_(float(t))
+            temb_dev = torch.empty((latents.shape[0] * rep, row.shape[1]), dtype=torch.float32, device=latents.device)
+            temb_dev.copy_(row.expand_as(temb_dev))
             # first call eager: one-time setup inside the launchers, scratch buffers of ops.py
-            self.unet.forward_nhwc(latents, t_dev, ctx, rep=rep)
+            self.unet.forward_nhwc(latents, t, ctx, rep=rep, temb=temb_dev)
             if self.unet.ctx_generation != key[4]:
                 key = key[:4] + (self.unet.ctx_generation,) + key[5:]
             pool = torch.cuda.MemPool()
             plan = hip.Plan()
             with torch.cuda.use_mem_pool(pool, device=latents.device), plan.record():
-                eps = self.unet.forward_nhwc(latents, t_dev, ctx, rep=rep)
-            self._plans = {key: (plan, t_dev, eps, pool, len(plan))}
+                eps = self.unet.forward_nhwc(latents, t, ctx, rep=rep, temb=temb_dev)
+            self._plans = {key: (plan, temb_dev, eps, pool, len(plan))}
             return eps                           # the recording run also executed
-        plan, t_dev, eps = entry[:3]
-        t_dev.fill_(float(t))
+        plan, temb_dev, eps = entry[:3]
+        temb_dev.copy_(row.expand_as(temb_dev))
         plan.replay()
         return eps
 
@@ -332,6 +345,15 @@ class FlexPipeline():
             # persistent latent buffer: the captured UNet graph / recorded plan reads this address
             latents = self.loop_latents(latents)
         is_lms = isinstance(self.scheduler, LMSDiscreteScheduler)
+        self._temb_tab = None
+        if (fused or planned) and hasattr(self.unet, 'time_bias_table'):
+            # the time embedding depends on t only: all of the request's timesteps in one pass (three GEMMs over len(timesteps) rows)
+            # instead of three GEMMs per step
+            ts = [float(t) for t in self.scheduler.timesteps[t_start:]]
+            keys = {}
+            for t in ts:
+                keys.setdefault(t, len(keys))
+            self._temb_tab = (keys, self.unet.time_bias_table(list(keys)))
         # The host only has to stay ahead of the device queue.  A generation-2 collection of the
         # cyclic GC walks every tracked object of the process (~175 k with the SD1.5 weights:
         # ~40 ms) and drains that queue, so collections wait until the images are decoded.

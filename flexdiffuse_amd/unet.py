@@ -401,21 +401,32 @@ class UNet2DConditionModel():
         e = ops.gemm(e, self.t2, act=ops.ACT_SILU)   # only SiLU(emb) is ever consumed
         return ops.gemm(e, self.temb_all, out_f32=True)
 
+    def time_bias_table(self, timesteps) -> torch.Tensor:
+        '''[len(timesteps)][sum Cout] fp32: time_bias of every timestep of a denoising loop in ONE pass (row i = what
+        time_bias(timesteps[i], 1) gives: each row is its own dot products, the batch does not enter).  The time embedding depends on
+        nothing but t, so the loop computes it once per request instead of once per step (FlexPipeline._unet_eps).'''
+        t = torch.tensor([float(v) for v in timesteps], dtype=torch.float32, device=self.device)
+        return self.time_bias(t, t.numel())
+
     def forward_nhwc(self, sample: torch.Tensor, timestep, ctx: torch.Tensor,
-                     rep: int = 1) -> torch.Tensor:
+                     rep: int = 1, temb: Optional[torch.Tensor] = None) -> torch.Tensor:
         '''(B,4,h,w) fp32 latents (replicated `rep` times along batch, e.g. for CFG) ->
-        noise prediction as NHWC fp32 [rep*B*h*w][4].'''
+        noise prediction as NHWC fp32 [rep*B*h*w][4].  `temb` [rep*B][sum Cout] fp32: the ResBlocks' time-embedding biases
+        already computed (time_bias / time_bias_table rows, one timestep for the whole batch); `timestep` is then not used.'''
         hip.require_device(sample, ctx)
         self.set_context(ctx)
         # The `rep` branches see the same latents and timestep, so everything before the first
         # cross-attention (conv_in, the first ResBlock, the first block's self-attention) is
         # computed once on B samples and fanned out there (bit-identical per sample).
-        share = rep > 1 and (not isinstance(timestep, torch.Tensor) or timestep.numel() == 1)
+        share = rep > 1 and (temb is not None or not isinstance(timestep, torch.Tensor) or timestep.numel() == 1)
         x = ops.nchw_to_nhwc(sample, rep=1 if share else rep, c_pad=self.conv_in.cin)
         Be = x.B * (rep if share else 1)
         if ctx.shape[0] != Be:
             raise ValueError(f'encoder_hidden_states batch {ctx.shape[0]} != latent batch {Be}')
-        temb = self.time_bias(timestep, Be)
+        if temb is None:
+            temb = self.time_bias(timestep, Be)
+        elif temb.shape != (Be, self.temb_total) or temb.dtype != torch.float32 or not temb.is_contiguous():
+            raise ValueError(f'temb must be a contiguous fp32 [{Be}][{self.temb_total}] tensor, got {tuple(temb.shape)} {temb.dtype}')
         fan = rep if share else 1      # > 1 while h still holds the shared B samples
         plan = self._cat_plan
         skips: List[tuple] = []        # (Act of the skip, its concat buffer or None, Ch)

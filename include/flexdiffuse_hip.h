@@ -244,8 +244,10 @@ typedef struct fd_gemm_desc {
      * convolution (norm2 behind conv1, the transformer's input norm behind conv2) then need no statistics pass over the tensor the
      * convolution has just written.  Honoured where one tile spans the row and lies in one sample (N == 320, the 256x320 / 128x320
      * tiles, lean epilogue, act NONE, batch 1, no split-K); FD_ESHAPE otherwise -- ask fd_gemm_gn_parts_chunks first.  Uses gn_groups.
-     * NULL = off. */
+     * gn_part_chunks: the chunk count the buffer was sized for (what fd_gemm_gn_parts_chunks answered); a launch whose tile would write
+     * another count -- a forced `tile` -- is refused instead of writing past the buffer.  NULL = off. */
     float* gn_part_out;
+    int32_t gn_part_chunks;
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);

@@ -1089,6 +1089,27 @@ def test_groupnorm_partial_sums_are_refused_where_no_tile_spans_the_row(dev):
         d.gn_groups = 32
         assert hip.lib().fd_gemm_gn_parts_chunks(ctypes.byref(d)) == 0
         buf = torch.empty((B, 64, 32, 2), dtype=torch.float32, device=dev)
-        d.gn_part_out = buf.data_ptr()
+        d.gn_part_out, d.gn_part_chunks = buf.data_ptr(), 64
         with pytest.raises(ValueError, match='gn_part_out'):
             hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+    # a buffer sized for the rule's tile is not written by a forced tile with another row count (256-row tile: 16 chunks per sample,
+    # 128-row tile: 32): FD_ESHAPE instead of a write past the end
+    B, H, C = 16, 64, 320
+    hd = ops.Act((torch.randn((B * H * H, C), generator=g) * 0.5).half().to(dev), B, H, H)
+    cw = ops.prep_conv(torch.randn((C, C, 3, 3), generator=g) * 0.02, torch.zeros(C), dev)
+    out, parts = ops.conv2d(hd, cw, gn_parts=32)
+    assert parts is not None and parts.chunks == 16
+    old = ops.FORCE_TILE
+    ops.FORCE_TILE = 32
+    try:
+        with pytest.raises(ValueError, match='gn_part_out'):
+            d = ops.fd_gemm_desc()
+            d.A, d.W, d.C, d.bias = hd.t.data_ptr(), cw.w.data_ptr(), out.t.data_ptr(), cw.bias.data_ptr()
+            d.M, d.N, d.K, d.ldw, d.ldc, d.lda = B * H * H, C, cw.kpad, cw.w.stride(0), C, C
+            d.rows_per_sample, d.alpha, d.batch = H * H, 1.0, 1
+            d.conv, d.in_h, d.in_w, d.in_c, d.out_h, d.out_w, d.kh, d.kw, d.stride, d.pad_t, d.pad_l = 1, H, H, C, H, H, 3, 3, 1, 1, 1
+            ops._sched(d, dev)
+            d.gn_groups, d.gn_part_out, d.gn_part_chunks = 32, parts.t.data_ptr(), parts.chunks
+            hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+    finally:
+        ops.FORCE_TILE = old

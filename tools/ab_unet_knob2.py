@@ -14,15 +14,19 @@ t_dev = torch.full((1,), 400.0, device=dev)
 plans = {}
 for arm in arms:
     saved = {}
+    temb = None
     if arm != '-':
         for kv in arm.split(','):
             k, v = kv.split('=')
+            if k == 'TEMB':      # the ResBlocks' time biases precomputed (FlexPipeline does this once per request): no time-embedding GEMMs in the forward
+                temb = unet.time_bias(400.0, 1).expand(16, -1).contiguous() if v != '0' else None
+                continue
             saved[k] = getattr(ops, k)
             setattr(ops, k, v != '0')
-    unet.forward_nhwc(x, t_dev, ctx, rep=2)
+    unet.forward_nhwc(x, t_dev, ctx, rep=2, temb=temb)
     pool = torch.cuda.MemPool(); plan = hip.Plan()
     with torch.cuda.use_mem_pool(pool, device=dev), plan.record():
-        eps = unet.forward_nhwc(x, t_dev, ctx, rep=2)
+        eps = unet.forward_nhwc(x, t_dev, ctx, rep=2, temb=temb)
     plans[arm] = (plan, pool, eps, len(plan))
     for k, v in saved.items(): setattr(ops, k, v)
 torch.cuda.synchronize()
