@@ -147,6 +147,32 @@ __global__ void k_copy2d(const uint4* __restrict__ src, size_t lds8, uint4* __re
     }
 }
 
+// dst[r * rows + i][0..cols) = src[i][0..cols) for r < rep: the CFG fan-out (B samples -> rep * B) in ONE launch -- every source granule
+// is read once and stored rep times (round 6: three launches and three boundaries less per forward than rep separate copies)
+__global__ void k_repeat_rows(const uint4* __restrict__ src, size_t lds8, uint4* __restrict__ dst, size_t ldd8, size_t rows, int cols8, int rep) {
+    const size_t total = rows * cols8;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = e % cols8;
+        const size_t r = e / cols8;
+        const uint4 v = src[r * lds8 + c];
+        for (int k = 0; k < rep; ++k) dst[((size_t)k * rows + r) * ldd8 + c] = v;
+    }
+}
+
+extern "C" int fd_repeat_rows_f16(const void* src, int lds, void* dst, int ldd, int64_t rows, int cols, int rep, void* stream) {
+    FD_PLAN(fd_repeat_rows_f16(src, lds, dst, ldd, rows, cols, rep, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
+    FD_CHECK_ARG(src && dst && rows > 0 && cols > 0 && rep >= 1 && lds >= cols && ldd >= cols, FD_EINVAL, "fd_repeat_rows_f16: args");
+    FD_CHECK_ARG(cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0, FD_ESHAPE,
+                 "fd_repeat_rows_f16: cols / strides must be multiples of 8 and the pointers 16-byte aligned");
+    const size_t total = (size_t)rows * (cols / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_repeat_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (size_t)(lds / 8), (uint4*)dst,
+                       (size_t)(ldd / 8), (size_t)rows, cols / 8, rep);
+    FD_CHECK_LAUNCH("k_repeat_rows");
+    return FD_OK;
+}
+
 extern "C" int fd_copy2d_f16(const void* src, int lds, void* dst, int ldd, int64_t rows, int cols,
                              void* stream) {
     FD_PLAN(fd_copy2d_f16(src, lds, dst, ldd, rows, cols, fd_s_));

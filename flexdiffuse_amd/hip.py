@@ -75,6 +75,7 @@ _SIGNATURES = {
     'fd_vit_assemble_f16': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     'fd_timestep_embedding_f16': (c_int, [P, c_int, P, c_int, c_int, P]),
     'fd_copy2d_f16': (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
+    'fd_repeat_rows_f16': (c_int, [P, c_int, P, c_int, c_int64, c_int, c_int, P]),
     'fd_plan_create': (c_int, [P]),
     'fd_plan_destroy': (c_int, [P]),
     'fd_plan_record_begin': (c_int, [P]),

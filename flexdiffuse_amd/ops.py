@@ -752,12 +752,13 @@ def contiguous_rows(x: torch.Tensor) -> torch.Tensor:
     return copy_rows(_empty(tuple(x.shape), torch.float16, x), x)
 
 
-def repeat_rows(x: torch.Tensor, rep: int) -> torch.Tensor:
-    '''fp16 [rows][C] -> [rep*rows][C]: the CFG fan-out of the shared UNet prefix.'''
+def repeat_rows(x: torch.Tensor, rep: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    '''fp16 [rows][C] -> [rep*rows][C] (into `out`, row stride free, if given): the CFG fan-out of the shared UNet prefix, one launch.'''
     rows, C = x.shape
-    out = _empty((rep * rows, C), torch.float16, x)
-    for r in range(rep):
-        copy_rows(out[r * rows:(r + 1) * rows], x)
+    if out is None:
+        out = _empty((rep * rows, C), torch.float16, x)
+    assert out.shape == (rep * rows, C) and out.dtype == x.dtype == torch.float16 and out.stride(1) == 1 and x.stride(1) == 1
+    hip.call('fd_repeat_rows_f16', x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, C, rep, hip.stream())
     return out
 
 

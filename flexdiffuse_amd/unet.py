@@ -456,8 +456,7 @@ class UNet2DConditionModel():
             if view is None:
                 push(Act(ops.repeat_rows(h.t, fan), Be, h.H, h.W), None, None)
             else:
-                for f in range(fan):
-                    ops.copy_rows(view[f * x.B * HW:(f + 1) * x.B * HW], h.t)
+                ops.repeat_rows(h.t, fan, out=view)
                 push(Act(view, Be, h.H, h.W), buf, ch)
         else:
             h = push(ops.conv2d(x, self.conv_in, out=view), buf, ch)
@@ -483,8 +482,7 @@ class UNet2DConditionModel():
                     if view is None:
                         h = Act(ops.repeat_rows(h.t, fan), Be, h.H, h.W)
                     else:
-                        for f in range(fan):
-                            ops.copy_rows(view[f * h.B * h.HW:(f + 1) * h.B * h.HW], h.t)
+                        ops.repeat_rows(h.t, fan, out=view)
                         h = Act(view, Be, h.H, h.W)
                 else:
                     # the next ResBlock reads exactly this tensor (no attention in between): its norm1 rides in conv2's finish

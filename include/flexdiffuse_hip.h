@@ -401,6 +401,9 @@ int fd_timestep_embedding_f16(const float* t, int t_stride, void* out, int B, in
 /* dst[r][0..cols) = src[r][0..cols) for fp16 matrices with row strides lds / ldd (elements);
  * cols, lds, ldd multiples of 8, pointers 16-byte aligned.  The CFG fan-out copies of the UNet. */
 int fd_copy2d_f16(const void* src, int lds, void* dst, int ldd, int64_t rows, int cols, void* stream);
+/* (ABI 11) dst[r * rows + i][0..cols) = src[i][0..cols) for r < rep, one launch: the CFG fan-out of the shared UNet prefix (B samples -> rep * B;
+ * the reference feeds the replicated batch from the start, pipeline/guide.py:46-58).  Same alignment rules as fd_copy2d_f16. */
+int fd_repeat_rows_f16(const void* src, int lds, void* dst, int ldd, int64_t rows, int cols, int rep, void* stream);
 /* CompositeGuide region blend (reference composition/guide.py:86-98), NCHW fp32 [C][H][W]:
  * dst[:, oy:oy+sh, ox:ox+sw] += blend * (src - dst) on the same box.  oy, ox >= 0: the host
  * resolves Python's slice semantics (negative starts count from the end of the axis) first;

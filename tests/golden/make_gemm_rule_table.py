@@ -21,7 +21,7 @@ def plan_all():
     for r in json.load(open(LAUNCHES))['launches']:
         d = ops.fd_gemm_desc()
         for name, typ in ops.fd_gemm_desc._fields_:
-            v = r[name]
+            v = r.get(name, None if typ is ctypes.c_void_p else 0)     # (fields newer than the dump: off)
             if typ is ctypes.c_void_p:
                 # a fake, never dereferenced address with the recorded alignment
                 setattr(d, name, None if v is None else 0x10000000 + 0x1000000 * (len(rows) % 7) + int(v))

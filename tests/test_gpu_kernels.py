@@ -1113,3 +1113,21 @@ def test_groupnorm_partial_sums_are_refused_where_no_tile_spans_the_row(dev):
             hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     finally:
         ops.FORCE_TILE = old
+
+
+def test_repeat_rows_is_one_launch_and_equals_the_copies(dev):
+    '''fd_repeat_rows_f16: the CFG fan-out (B samples -> rep * B) as one launch, into a contiguous tensor or into a column slice of a wider
+    buffer (the skip tensors' concat buffers); equals rep separate fd_copy2d_f16 calls.'''
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((1000, 320), generator=g).half().to(dev)
+    xs = torch.zeros((1000, 384), dtype=torch.float16, device=dev)
+    xs[:, 32:352] = x
+    for src in (x, xs[:, 32:352]):
+        out = ops.repeat_rows(src, 3)
+        assert torch.equal(out, torch.cat([x, x, x], 0))
+        buf = torch.full((2000, 640), 7.0, dtype=torch.float16, device=dev)
+        ops.repeat_rows(src, 2, out=buf[:, 320:])
+        assert torch.equal(buf[:, 320:], torch.cat([x, x], 0)) and bool((buf[:, :320] == 7.0).all())
+    with pytest.raises(ValueError):
+        ops.repeat_rows(x[:, :36], 2)                  # 36 columns: not a multiple of 8
