@@ -242,6 +242,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     const int tile_n = id % g.tiles_n, tile_m = id / g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z;
+    const bool tr_tile = EPI == 13 && __builtin_amdgcn_readfirstlane(n0 >= g.tr_n0 ? 1 : 0) != 0;   // fd_gemm_desc.trans_n0
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(g.A + (size_t)z * g.strideA), 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
@@ -265,7 +266,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
     }
     // per-sample bias (ResBlock time embedding): one row when the whole tile lies in one sample
     const int b_first = m0 / g.rows_per_batch;
-    const bool b2_staged = g.bias2 && g.bias_lds && (min(m0 + BM, g.M) - 1) / g.rows_per_batch == b_first;
+    // (EPI 13: the LayerNorm fold's column sums are one row for every sample -- ldb2 == 0 --, staged whatever the sample boundary)
+    const bool b2_staged = g.bias2 && g.bias_lds && ((EPI == 13 && g.ln_stats != nullptr) || (min(m0 + BM, g.M) - 1) / g.rows_per_batch == b_first);
     if (b2_staged || (EPI != 0 && EPI != 7)) {
         const __amdgpu_buffer_rsrc_t rsB2 = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(b2_staged ? (const void*)(g.bias2 + (size_t)b_first * g.ldb2) : (const void*)g.W), 0,
@@ -483,6 +485,23 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
 #pragma unroll
             for (int j = 0; j < NI; ++j)
                 fb[j] = *reinterpret_cast<const half8*>(st + frag_b + j * 2048 + sw);
+            if constexpr (EPI == 13) {
+                // transposed tail: the tiles that store transposed take the operands in the TRANS order (a lane then owns 4 consecutive
+                // rows of one column); one workgroup-uniform branch per K step, no select on the results
+                if (tr_tile) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -491,6 +510,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
                                                                                acc[i][j], 0, 0, 0)
                                       : __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i],
                                                                                acc[i][j], 0, 0, 0);
+            }
             }
         }
         // keep the wait for the NEXT K-tile's DMA behind ALL of this tile's MFMAs: left alone, hipcc sinks the second
@@ -517,6 +537,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
         gemm_epilogue_fast<MI, NI, FD_ACT_NONE, EPI == 9, true, false, true, WN>(
             g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN),
             reinterpret_cast<float*>(smem), wm * WTM + fr, wn, m0);
+    } else if constexpr (EPI == 13) {
+        // LayerNorm-fold GEMM with a transposed tail (fd_gemm_desc.trans_n0): q|k tiles through the lean fold epilogue, V tiles through the
+        // transposed-store epilogue into C2 with the tail's columns re-based to 0
+        if (tr_tile) {
+            GemmArgs gt = g;
+            gt.C = g.C2;
+            gt.N = g.N - g.tr_n0;
+            gt.bias = g.bias ? g.bias + g.tr_n0 : nullptr;
+            gt.bias2 = g.bias2 ? g.bias2 + g.tr_n0 : nullptr;
+            gemm_epilogue<BM, BN, true, WM, WN, true>(gt, acc, m0, n0 - g.tr_n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
+                                                      b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr, -1);
+        } else {
+            gemm_epilogue_fast<MI, NI, FD_ACT_NONE, false, true, true>(
+                g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN));
+        }
     } else if constexpr (EPI == 11 || EPI == 12) {   // lean (+ residual) + GroupNorm partial sums of the tile's output (gn_part_out)
         if constexpr (NS == 3) __syncthreads();
         gemm_epilogue_fast<MI, NI, FD_ACT_NONE, EPI == 12, true, false, false, WN, WM>(
@@ -961,7 +996,7 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         if (lds > 64 * 1024 && fd_first_on_device(&configured)) {
             FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dma<BM, BN, CONV, WM, TRANS, NS, WN, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if constexpr (BN != 320)   // the 256x320 tile has no persistent form (it would spill)
+            if constexpr (BN != 320 && EPI != 13)   // the 256x320 tile has no persistent form (it would spill); nor has the transposed tail
                 FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS, WN, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
@@ -970,14 +1005,14 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         const int occ = (BM >= 256 || lds > 80 * 1024) ? 1 : (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);  // workgroups / CU
         const int slots = 256 * occ;
         const int nkt = (g.K + BK - 1) / BK / g.split_k;
-        const bool persistent = NS == 2 && BN != 320 && g.K2 == 0 && !g.phase && !g.ln_stats_out && g.strideBias == 0 && (g_persist_mode == 2 ||
+        const bool persistent = NS == 2 && BN != 320 && EPI != 13 && g.K2 == 0 && !g.phase && !g.ln_stats_out && g.strideBias == 0 && (g_persist_mode == 2 ||
                                 (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots));
         if constexpr (EPI >= 1 && EPI <= 3) {
             // the persistent loop does not stage the per-sample bias: generic epilogue there
             if (persistent && g.bias2) return launch_mode<BM, BN, TRANS, CONV, WM, NS, WN, 0>(g, batch, st);
         }
         if (persistent) {
-            if constexpr (BN != 320) {
+            if constexpr (BN != 320 && EPI != 13) {
                 dim3 pgrid(g.tiles_m * g.tiles_n > slots ? slots : g.tiles_m * g.tiles_n, g.split_k, batch);
                 hipLaunchKernelGGL((k_gemm_f16_dmap<BM, BN, CONV, WM, TRANS, WN, EPI>), pgrid, dim3(64 * WM * WN), lds,
                                    st, g, (unsigned)a_bytes, (unsigned)w_bytes);
@@ -1258,6 +1293,34 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
         g.ln_stats = d->ln_stats;
         g.bias2 = d->ln_colsum;   // one row for every sample: row stride 0
         g.ldb2 = 0;
+    }
+    if (d->trans_n0 > 0) {
+        // transposed tail: one launch for the stacked [q | k | v] projection of a self-attention (see the header)
+        FD_CHECK_ARG(d->C2 && d->ln_stats && !d->conv && !d->trans_out && d->act == FD_ACT_NONE && !d->residual && !d->out_f32 && batch == 1 &&
+                         !d->K2 && !d->ln_stats_out && !d->gn_out && !d->gn_part_out,
+                     FD_EINVAL, "fd_gemm_f16: trans_n0 needs C2 and a plain LayerNorm-fold linear GEMM (act NONE, no residual / batch / appended operand)");
+        FD_CHECK_ARG(d->M % 128 == 0 && d->N % 160 == 0 && d->trans_n0 % 160 == 0 && d->trans_n0 < d->N && g.rows_per_batch % 32 == 0 &&
+                         d->M % g.rows_per_batch == 0 && d->trans_ld % 8 == 0 && d->trans_ld >= g.rows_per_batch && d->trans_sample_stride % 8 == 0 &&
+                         (uintptr_t)d->C2 % 16 == 0 && (d->ldc & 7) == 0 && g_use_dma && g_fast_epi && g_bias_lds,
+                     FD_ESHAPE, "fd_gemm_f16: trans_n0 needs M %% 128 == 0, N and trans_n0 multiples of 160, rows_per_sample %% 32 == 0 and | M, "
+                                "trans_ld %% 8 == 0 and >= rows_per_sample, ldc %% 8 == 0, 16-byte aligned C2, the LDS-DMA path with the lean epilogue");
+        const unsigned long long ab = 2ull * ((unsigned long long)(d->M - 1) * d->lda + d->K), wb = 2ull * ((unsigned long long)(d->N - 1) * d->ldw + d->K);
+        FD_CHECK_ARG(ab < 0x7fffffffull && wb < 0x7fffffffull, FD_ESHAPE, "fd_gemm_f16: trans_n0: operands >= 2 GiB");
+        g.tr_n0 = d->trans_n0;
+        g.C2 = (half_t*)d->C2;
+        g.split_k = 1;
+        g.bias_lds = g_bias_lds;
+        if (choice) {
+            choice[0] = 9;
+            choice[1] = 1;
+            return FD_OK;
+        }
+        hipStream_t st2 = (hipStream_t)stream;
+        const double fl = 2.0 * (double)d->M * d->N * d->K;
+        fd_prof_begin(FD_FAMILY_GEMM, st2, fl, fl, fd_tag(14u, g.M, g.N, g.K, g.tr_n0));
+        const int rc2 = launch_mode<128, 160, false, false, 4, 2, 2, 13>(g, 1, st2);
+        fd_prof_end(FD_FAMILY_GEMM, st2);
+        return rc2;
     }
     if (d->gn_out) {
         // GroupNorm(+SiLU) of the output inside the split-K finish (k_splitk_finish_gn)

@@ -56,6 +56,9 @@ struct GemmArgs {
     // GroupNorm partial sums of the OUTPUT from the lean epilogue of a row-spanning tile (fd_gemm_desc.gn_part_out):
     // [sample][rows_per_batch / BM][gn_groups][2] = (sum, sum of squares) of the fp16-rounded values, the layout k_gn_stats writes
     float* gn_part_out;
+    // transposed tail (fd_gemm_desc.trans_n0): tiles with n0 >= tr_n0 run the transposed-store epilogue into C2
+    int tr_n0;
+    half_t* C2;
 };
 
 // Exact-form GELU  x * Phi(x),  Phi(x) = 0.5 * (1 + erf(x / sqrt 2)),  with erf from Abramowitz &

@@ -36,7 +36,7 @@ class fd_gemm_desc(ctypes.Structure):
                 ('batch_stride_bias', c_int64),
                 ('gn_out', c_void_p), ('gn_gamma', c_void_p), ('gn_beta', c_void_p),
                 ('gn_groups', c_int32), ('gn_silu', c_int32), ('gn_eps', c_float), ('gn_skip_c', c_int32),
-                ('gn_part_out', c_void_p), ('gn_part_chunks', c_int32)]
+                ('gn_part_out', c_void_p), ('gn_part_chunks', c_int32), ('trans_n0', c_int32), ('C2', c_void_p)]
 
 
 class fd_attention_desc(ctypes.Structure):
@@ -363,6 +363,35 @@ def gemm_vt(a: torch.Tensor, w: LinW, B: int, rows_per_sample: int, ld: int,
         d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), w.colsum.data_ptr()
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     return out
+
+
+QKV_MERGE = os.environ.get('FD_UNET_QKV', '1') != '0'     # self-attention q | k | v as ONE launch with a transposed tail (A/B: 0 = two launches)
+
+
+def qkv_merge_supported(M: int, C: int, rows_per_sample: int) -> bool:
+    '''Shapes gemm_qkv covers (fd_gemm_desc.trans_n0): 128-row tiles, 160-column tiles, whole 32-row blocks per sample, unpadded V^T rows.'''
+    return QKV_MERGE and M % 128 == 0 and C % 160 == 0 and rows_per_sample % 32 == 0 and M % rows_per_sample == 0
+
+
+def gemm_qkv(a: torch.Tensor, w: LinW, B: int, rows_per_sample: int, ln_stats: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    '''LayerNorm-fold projection with the weights stacked [q | k | v] (3C rows, prep_linear_ln) in ONE launch: -> (q|k [M][2C] fp16
+    row-major, V^T [B][C][rows_per_sample] fp16): the last C columns of the output are stored transposed (fd_gemm_desc.trans_n0 / C2).
+    The hidden states are read once; same bits as gemm(..., wqk) + gemm_vt(..., wv).'''
+    M, K = a.shape
+    C = w.N // 3
+    assert w.N == 3 * C and K == w.K and M == B * rows_per_sample and w.colsum is not None and ln_stats.shape == (M, 2)
+    qk = _empty((M, 2 * C), torch.float16, a)
+    vt = _empty((B, C, rows_per_sample), torch.float16, a)
+    d = fd_gemm_desc()
+    d.A, d.W, d.C, d.C2 = a.data_ptr(), w.w.data_ptr(), qk.data_ptr(), vt.data_ptr()
+    d.bias = _p(w.bias)
+    d.M, d.N, d.K = M, w.N, K
+    d.lda, d.ldw, d.ldc = a.stride(0), w.w.stride(0), 2 * C
+    d.rows_per_sample, d.alpha, d.batch = rows_per_sample, 1.0, 1
+    d.trans_n0, d.trans_ld, d.trans_sample_stride = 2 * C, rows_per_sample, C * rows_per_sample
+    d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), w.colsum.data_ptr()
+    hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
+    return qk, vt
 
 
 def bgemm(a: torch.Tensor, w: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:

@@ -81,6 +81,9 @@ class _Attn:
             (g1, b1), (g2, b2), (g3, b3) = [(g(f'{tb}.norm{i}.weight'), g(f'{tb}.norm{i}.bias')) for i in (1, 2, 3)]
             self.qk1 = ops.prep_linear_ln(wqk, None, g1, b1, dev)
             self.v1 = ops.prep_linear_ln(g(f'{tb}.attn1.to_v.weight'), None, g1, b1, dev)
+            # ... and q | k | v stacked for the one-launch form (ops.gemm_qkv: the V columns are stored transposed by the same launch)
+            self.qkv1 = ops.prep_linear_ln(torch.cat([wqk, g(f'{tb}.attn1.to_v.weight').float()], 0), None, g1, b1, dev) \
+                if ops.QKV_MERGE and wq.shape[0] % 160 == 0 else None
             self.q2 = ops.prep_linear_ln(wq2, None, g2, b2, dev)
             self.ff1 = ops.prep_linear_ln(g(f'{tb}.ff.net.0.proj.weight'), g(f'{tb}.ff.net.0.proj.bias'), g3, b3, dev,
                                           geglu=True)
@@ -88,6 +91,7 @@ class _Attn:
             # self-attention q and k share their input: one GEMM with the weights stacked along N
             self.qk1 = ops.prep_linear(wqk, None, dev)
             self.v1 = ops.prep_linear(g(f'{tb}.attn1.to_v.weight'), None, dev)
+            self.qkv1 = None
             self.q2 = ops.prep_linear(wq2, None, dev)
             self.ff1 = ops.prep_geglu(g(f'{tb}.ff.net.0.proj.weight'), g(f'{tb}.ff.net.0.proj.bias'), dev)
         self.o1 = ops.prep_linear(g(f'{tb}.attn1.to_out.0.weight'), g(f'{tb}.attn1.to_out.0.bias'), dev)
@@ -263,6 +267,17 @@ class UNet2DConditionModel():
         self._ctx_ref = ctx  # keep the tensor alive so its data_ptr cannot be recycled
 
     # ---- blocks -----------------------------------------------------------------------------
+    @staticmethod
+    def _qkv_level(M: int) -> bool:
+        '''Row counts at which the one-launch q | k | v projection is used.  Measured per launch against the two launches it replaces
+        (tools/ab_qkv.py, profiles/r06_session_ab.txt sec. 7): equal at 65536 / 32768 rows, 0.7 us faster at 4096, 11.6 us faster at 1024,
+        5.8 us SLOWER at 16384 rows x 640 channels (there the q|k GEMM alone runs on a ping-pong tile) -- so not between 8192 and 16384 rows;
+        a launch boundary less either way.  FD_UNET_QKV_MIN_ROWS / _MAX_ROWS override the window (A/B).'''
+        lo, hi = os.environ.get('FD_UNET_QKV_MIN_ROWS'), os.environ.get('FD_UNET_QKV_MAX_ROWS')
+        if lo is not None or hi is not None:
+            return int(lo or 0) <= M <= int(hi or (1 << 30))
+        return not (8192 <= M <= 16384)
+
     def _gn1(self, r: Optional[_Res]) -> Optional[ops.GNSpec]:
         '''norm1 + SiLU of ResBlock `r` as a spec its input's PRODUCER can take (ops.conv2d(..., gn=)).'''
         return None if r is None else ops.GNSpec(r.n1g, r.n1b, self.G, 1e-5, True)
@@ -335,8 +350,11 @@ class UNet2DConditionModel():
             h = ops.gemm(h.t, a.proj_in, ln_stats_out=st)
         if a.ln_fold:
             st = fin(st, h)
-            qk = ops.gemm(h, a.qk1, ln_stats=st)
-            vt = ops.gemm_vt(h, a.v1, B, HW, (HW + 7) // 8 * 8, ln_stats=st)
+            if a.qkv1 is not None and ops.qkv_merge_supported(B * HW, C, HW) and self._qkv_level(B * HW):
+                qk, vt = ops.gemm_qkv(h, a.qkv1, B, HW, st)
+            else:
+                qk = ops.gemm(h, a.qk1, ln_stats=st)
+                vt = ops.gemm_vt(h, a.v1, B, HW, (HW + 7) // 8 * 8, ln_stats=st)
         else:
             n = ops.layernorm(h, *a.ln[0])
             qk = ops.gemm(n, a.qk1)

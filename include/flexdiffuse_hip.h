@@ -248,6 +248,15 @@ typedef struct fd_gemm_desc {
      * another count -- a forced `tile` -- is refused instead of writing past the buffer.  NULL = off. */
     float* gn_part_out;
     int32_t gn_part_chunks;
+    /* (ABI 11) TRANSPOSED TAIL: columns n >= trans_n0 of the output are stored transposed into C2 -- [sample][N - trans_n0][trans_ld]
+     * (row n - trans_n0, column m within the sample; trans_ld / trans_sample_stride as for trans_out) -- while columns n < trans_n0 go to C
+     * [M][ldc] as usual.  The self-attention of diffusers' BasicTransformerBlock.attn1 inside `unet(...)` (reference pipeline/guide.py:56-58)
+     * projects q, k and v from the same LayerNorm'd rows: with the weights stacked [q | k | v] this is ONE launch that reads the hidden
+     * states once and writes q|k row-major and V^T in the layout fd_attention_f16 takes, instead of two launches over the same rows.
+     * Linear GEMM with the LayerNorm fold (ln_stats), act NONE, no residual / bias2 / batch; M %% 128 == 0, N and trans_n0 multiples of
+     * 160, rows_per_sample %% 32 == 0, trans_ld %% 8 == 0.  0 = off. */
+    int32_t trans_n0;
+    void* C2;
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);

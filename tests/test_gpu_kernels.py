@@ -1131,3 +1131,46 @@ def test_repeat_rows_is_one_launch_and_equals_the_copies(dev):
         assert torch.equal(buf[:, 320:], torch.cat([x, x], 0)) and bool((buf[:, :320] == 7.0).all())
     with pytest.raises(ValueError):
         ops.repeat_rows(x[:, :36], 2)                  # 36 columns: not a multiple of 8
+
+
+@pytest.mark.parametrize('B,HW,C', [(16, 4096, 320), (8, 4096, 320), (16, 1024, 640), (16, 256, 1280), (16, 64, 1280), (2, 576, 640)])
+def test_qkv_projection_with_a_transposed_tail(dev, B, HW, C):
+    '''fd_gemm_desc.trans_n0 / C2 (ops.gemm_qkv): the self-attention's q | k | v projection from LayerNorm-folded weights in ONE launch --
+    q|k row-major, V transposed into the layout fd_attention_f16 takes -- against the two launches it replaces (same bits: no split over K,
+    the same MFMA summation order whatever the tile) and against a torch fp32 LayerNorm + linear; repeats bit for bit.'''
+    from flexdiffuse_amd import ops
+    M = B * HW
+    g = torch.Generator().manual_seed(B + HW + C)
+    x = (torch.randn((M, C), generator=g) * (0.5 + torch.rand((M, 1), generator=g)) + torch.randn((M, 1), generator=g)).half()
+    gamma, beta = 1 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    wqk, wv = torch.randn((2 * C, C), generator=g) * C ** -0.5, torch.randn((C, C), generator=g) * C ** -0.5
+    lqk, lv = ops.prep_linear_ln(wqk, None, gamma, beta, dev), ops.prep_linear_ln(wv, None, gamma, beta, dev)
+    lqkv = ops.prep_linear_ln(torch.cat([wqk, wv], 0), None, gamma, beta, dev)
+    xd = x.to(dev)
+    st = ops.ln_row_stats(xd)
+    assert ops.qkv_merge_supported(M, C, HW)
+    qk, vt = ops.gemm_qkv(xd, lqkv, B, HW, st)
+    qk2 = ops.gemm(xd, lqk, ln_stats=st)
+    vt2 = ops.gemm_vt(xd, lv, B, HW, HW, ln_stats=st)
+    assert qk.shape == (M, 2 * C) and vt.shape == (B, C, HW)
+    assert torch.equal(qk, qk2), float((qk.float() - qk2.float()).abs().max())
+    assert torch.equal(vt, vt2), float((vt.float() - vt2.float()).abs().max())
+    xn = F.layer_norm(x.float().to(dev), (C,), gamma.to(dev), beta.to(dev), 1e-5)
+    close(qk, xn @ wqk.to(dev).t(), rtol=6e-3, atol=6e-3)
+    close(vt, (xn @ wv.to(dev).t()).view(B, HW, C).permute(0, 2, 1), rtol=6e-3, atol=6e-3)
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(20):
+        q3, v3 = ops.gemm_qkv(xd, lqkv, B, HW, st)
+        bad += (q3 != qk).sum() + (v3 != vt).sum()
+    assert int(bad) == 0
+
+
+def test_transposed_tail_is_refused_outside_its_shapes(dev):
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(2)
+    C = 320
+    lqkv = ops.prep_linear_ln(torch.randn((3 * C, C), generator=g) * 0.05, None, torch.ones(C), torch.zeros(C), dev)
+    x = torch.randn((200, C), generator=g).half().to(dev)          # 200 rows: not a multiple of 128
+    assert not ops.qkv_merge_supported(200, C, 100)
+    with pytest.raises(ValueError, match='trans_n0'):
+        ops.gemm_qkv(x, lqkv, 2, 100, ops.ln_row_stats(x))
