@@ -643,7 +643,7 @@ def main():
             pipe.use_graph, pipe.use_plan = False, True
         one_pass()                        # records the plan (and warms the mode) with the recorder off
         torch.cuda.synchronize()
-        for attempt in range(2):
+        for attempt in range(2 if world == 1 else 1):      # (N > 1: every rank takes part in each pass's all-gather -- no unilateral retry)
             empty_ms = hip.prof_calibrate(256)
             hip.prof_set_stride(EVENT_STRIDE)
             hip.prof_enable(True)
