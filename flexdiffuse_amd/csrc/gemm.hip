@@ -1338,6 +1338,10 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
         g.gn_groups = d->gn_groups; g.gn_silu = d->gn_silu; g.gn_skip_c = d->gn_skip_c;
         g.gn_eps = d->gn_eps > 0.f ? d->gn_eps : 1e-5f;
     }
+    if (d->sk_sync) {
+        FD_CHECK_ARG(!d->gn_out && (uintptr_t)d->sk_sync % 4 == 0, FD_EINVAL, "fd_gemm_f16: sk_sync excludes gn_out (the GroupNorm would read an unfinished tile)");
+        g.sk_sync = (unsigned*)d->sk_sync;
+    }
     if (d->gn_part_out || (choice && choice[0] == -1)) {
         g.gn_groups = d->gn_groups;
         g.gn_part_out = d->gn_part_out;
@@ -1678,7 +1682,9 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
 #ifdef FD_SPLITK_NO_FINISH   // timing-only variant (tools/seam_probe.py): the chain without the finish launch
     if (false) {
 #else
-    if (rc == FD_OK && g.split_k > 1 && g.gn_out) {
+    if (rc == FD_OK && g.split_k > 1 && g.sk_sync && best_tile >= 30) {
+        // (experimental in-launch reduction: the partial launch finished its own tiles)
+    } else if (rc == FD_OK && g.split_k > 1 && g.gn_out) {
         switch (g.split_k) {
             case 2: rc = launch_finish_gn<2>(g, st); break;
             case 4: rc = launch_finish_gn<4>(g, st); break;

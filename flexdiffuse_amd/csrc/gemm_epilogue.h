@@ -59,6 +59,8 @@ struct GemmArgs {
     // transposed tail (fd_gemm_desc.trans_n0): tiles with n0 >= tr_n0 run the transposed-store epilogue into C2
     int tr_n0;
     half_t* C2;
+    // experimental in-launch split-K reduction (fd_gemm_desc.sk_sync): [tiles] arrival counters, then [tiles] departure counters
+    unsigned* sk_sync;
 };
 
 // Exact-form GELU  x * Phi(x),  Phi(x) = 0.5 * (1 + erf(x / sqrt 2)),  with erf from Abramowitz &

@@ -395,6 +395,68 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
 #endif
                 *reinterpret_cast<floatx4*>(P + (size_t)i * 16 * g.N + j * 16) = acc[i][j];
             }
+    } else if constexpr (EPI == 14) {
+        // EXPERIMENTAL in-launch split-K reduction (fd_gemm_desc.sk_sync; measured, not used by the product: DESIGN.md sec. 9 item 1b).
+        // (1) publish this slice's fp32 tile exactly as EPI 10 does
+        {
+            float* __restrict__ P = g.ws + (size_t)kslice * g.M * g.N + (size_t)(m0 + wm * WTM + fr) * g.N + n0 + wn * WTN + fq * 4;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) *reinterpret_cast<floatx4*>(P + (size_t)i * 16 * g.N + j * 16) = acc[i][j];
+        }
+        // (2) arrive: the barrier orders every wave's stores before thread 0's agent-scope release (cumulativity), which writes the XCD's
+        //     dirty lines back so that the tile's other slices -- on other XCDs -- can read them; (3) wait, bounded: a launch that is not
+        //     fully resident would otherwise spin forever
+        const int tile_id = tile_m * g.tiles_n + tile_n;
+        unsigned* arrive = g.sk_sync + tile_id;
+        unsigned* depart = g.sk_sync + g.tiles_m * g.tiles_n + tile_id;
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)g.split_k && ++spins < (1 << 22))
+                __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+        // (4) finish rows [kslice * BM / S, (kslice + 1) * BM / S) of the tile: the slabs in slice order, then the finish kernel's arithmetic
+        {
+            const int S = g.split_k, rows = BM / S, r0 = m0 + kslice * rows;
+            constexpr int C4 = BN / 4;
+            const size_t slab = (size_t)g.M * g.N;
+            for (int e = tid; e < rows * C4; e += 512) {
+                const int r = e / C4, c4 = e - r * C4;
+                const int m = r0 + r, n = n0 + c4 * 4;
+                const float* src = g.ws + (size_t)m * g.N + n;
+                float4 a = *reinterpret_cast<const float4*>(src);
+                for (int sidx = 1; sidx < S; ++sidx) {
+                    const float4 q = *reinterpret_cast<const float4*>(src + (size_t)sidx * slab);
+                    a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+                }
+                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), b2 = bb;
+                if (g.bias) bb = *reinterpret_cast<const float4*>(g.bias + n);
+                if (g.bias2) b2 = *reinterpret_cast<const float4*>(g.bias2 + (size_t)(m / g.rows_per_batch) * g.ldb2 + n);
+                float v[4] = {fmaf(a.x, g.alpha, bb.x + b2.x), fmaf(a.y, g.alpha, bb.y + b2.y), fmaf(a.z, g.alpha, bb.z + b2.z), fmaf(a.w, g.alpha, bb.w + b2.w)};
+                if (g.res) {
+                    const half4 rr = *reinterpret_cast<const half4*>(g.res + (size_t)m * g.ldr + n);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += (float)rr[k];
+                }
+                half4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (half_t)v[k];
+                *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(g.C) + (size_t)m * g.ldc + n) = o;
+            }
+        }
+        // (5) depart: the last slice to leave re-arms the tile's counters for the next launch
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned)g.split_k - 1u) {
+                __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     } else if constexpr (EPI == 0 || EPI == 7)
         gemm_epilogue<BM, BN, false, WM_, WN_, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
                                                          b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr, kslice);
@@ -461,7 +523,7 @@ template <int WM_, int WN_, int MI, int NI, bool CONV, int EPI>
 static int pp_launch_k(GemmArgs& g, int batch, hipStream_t st) {
     // the appended phase exists for the plain / residual / split-K epilogues of convolutions (ResBlock shortcut) and linears
     // (proj_out folded through FF-out)
-    if constexpr (EPI == 1 || EPI == 2 || EPI == 10 || EPI == 0 || EPI == 11 || EPI == 12) {
+    if constexpr (EPI == 1 || EPI == 2 || EPI == 10 || EPI == 0 || EPI == 11 || EPI == 12 || EPI == 14) {
         if (g.K2) return pp_launch_k2<WM_, WN_, MI, NI, CONV, EPI, true>(g, batch, st);
     } else {
         if (g.K2) {
@@ -477,6 +539,16 @@ template <int WM_, int WN_, int MI, int NI>
 static int pp_launch(GemmArgs& g, int batch, hipStream_t st) {
     constexpr int BM = WM_ * MI * 16, BN = WN_ * NI * 16;
     const bool conv = g.mode == MODE_CONV;
+    if (g.split_k > 1 && (g.N & 3) == 0 && g.sk_sync) {
+        // experimental in-launch reduction: 320-wide tiles only (the split-K launches of the forward), every workgroup resident at once
+        if constexpr (BN == 320) {
+            if ((g.M / BM) * (g.N / BN) * g.split_k <= 256 && BM % g.split_k == 0 && batch == 1 && !g.out_f32 && g.act == FD_ACT_NONE && (g.ldc & 3) == 0 &&
+                (!g.res || (g.ldr & 3) == 0) && (g.ldb2 & 3) == 0)
+                return conv ? pp_launch_k<WM_, WN_, MI, NI, true, 14>(g, batch, st) : pp_launch_k<WM_, WN_, MI, NI, false, 14>(g, batch, st);
+        }
+        fd_set_error("fd_gemm_f16: sk_sync (in-launch split-K reduction) needs a 320-wide ping-pong tile, tiles x split_k <= 256 workgroups, a plain fp16 output");
+        return FD_ESHAPE;
+    }
     if (g.split_k > 1 && (g.N & 3) == 0)
         return conv ? pp_launch_k<WM_, WN_, MI, NI, true, 10>(g, batch, st) : pp_launch_k<WM_, WN_, MI, NI, false, 10>(g, batch, st);
     const bool lean = g.split_k == 1 && !g.out_f32 && !g.trans_out && g.bias_lds && (g.ldc & 7) == 0 &&

@@ -36,7 +36,8 @@ class fd_gemm_desc(ctypes.Structure):
                 ('batch_stride_bias', c_int64),
                 ('gn_out', c_void_p), ('gn_gamma', c_void_p), ('gn_beta', c_void_p),
                 ('gn_groups', c_int32), ('gn_silu', c_int32), ('gn_eps', c_float), ('gn_skip_c', c_int32),
-                ('gn_part_out', c_void_p), ('gn_part_chunks', c_int32), ('trans_n0', c_int32), ('C2', c_void_p)]
+                ('gn_part_out', c_void_p), ('gn_part_chunks', c_int32), ('trans_n0', c_int32), ('C2', c_void_p),
+                ('sk_sync', c_void_p)]
 
 
 class fd_attention_desc(ctypes.Structure):
@@ -283,6 +284,10 @@ FORCE_SPLIT = 0
 WS_SLOT = 0         # scratch-buffer set; work enqueued concurrently on another stream must use another slot
 
 
+SPLITK_INLAUNCH = os.environ.get('FD_SPLITK_INLAUNCH', '0') == '1'    # EXPERIMENTAL in-launch split-K reduction (fd_gemm_desc.sk_sync); see DESIGN sec. 9 item 1b
+_sk_sync = {}
+
+
 def _sched(d: 'fd_gemm_desc', dev: torch.device):
     key = (dev.index if dev.index is not None else 0, WS_SLOT)
     ws = _splitk_ws.get(key)
@@ -291,6 +296,23 @@ def _sched(d: 'fd_gemm_desc', dev: torch.device):
         _splitk_ws[key] = ws
     d.workspace, d.workspace_bytes = ws.data_ptr(), SPLITK_WS_BYTES
     d.tile, d.split_k = FORCE_TILE, FORCE_SPLIT
+
+
+def _inlaunch_request(d: 'fd_gemm_desc', dev: torch.device, tile: int, split: int) -> bool:
+    '''Experimental: hand the launch the tile counters of the in-launch split-K reduction when it would run on a 320-wide ping-pong tile with
+    every workgroup resident (tiles x split <= 256).'''
+    if not SPLITK_INLAUNCH or split <= 1 or tile not in (30, 32):
+        return False
+    bm = 256 if tile == 30 else 128
+    if d.N % 320 or d.M % bm or (d.M // bm) * (d.N // 320) * split > 256 or bm % split:
+        return False
+    key = (dev.index if dev.index is not None else 0, WS_SLOT)
+    t = _sk_sync.get(key)
+    if t is None:
+        t = torch.zeros(8192, dtype=torch.int32, device=dev)
+        _sk_sync[key] = t
+    d.sk_sync = t.data_ptr()
+    return True
 
 
 def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
@@ -505,7 +527,8 @@ def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), 
         lib = hip.lib()
         tile, split = c_int32(0), c_int32(0)
         hip.check(lib.fd_gemm_plan(ctypes.byref(d), ctypes.byref(tile), ctypes.byref(split)), 'fd_gemm_plan')
-        fuse = (GN_FINISH_FUSE and split.value > 1 and act == ACT_NONE and not out_f32 and w.cout % 8 == 0 and out.stride(0) % 8 == 0
+        inl = _inlaunch_request(d, x.t.device, tile.value, split.value)
+        fuse = (not inl and GN_FINISH_FUSE and split.value > 1 and act == ACT_NONE and not out_f32 and w.cout % 8 == 0 and out.stride(0) % 8 == 0
                 and (residual is None or (residual.stride(0) % 8 == 0 and residual.data_ptr() % 16 == 0))
                 and (bias2 is None or (ld_bias2 % 4 == 0 and bias2.data_ptr() % 16 == 0))
                 and lib.fd_gemm_can_fuse_groupnorm(M, w.cout, Ho * Wo, gn.G, split.value))
@@ -522,6 +545,10 @@ def conv2d(x: Act, w: ConvW, *, stride: int = 1, pad: Tuple[int, int] = (1, 1), 
         d.gn_groups, d.gn_silu, d.gn_eps, d.gn_skip_c = gn.G, int(gn.silu), gn.eps, int(not keep)
         hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
         return (Act(out, x.B, Ho, Wo) if keep else None), Act(y, x.B, Ho, Wo)
+    if SPLITK_INLAUNCH and act == ACT_NONE and not out_f32:      # (experimental; conv2d(..., gn=) has asked above)
+        tile, split = c_int32(0), c_int32(0)
+        hip.check(hip.lib().fd_gemm_plan(ctypes.byref(d), ctypes.byref(tile), ctypes.byref(split)), 'fd_gemm_plan')
+        _inlaunch_request(d, x.t.device, tile.value, split.value)
     if gn_parts:
         parts = _gn_parts_request(d, x.B, gn_parts, x.t)
         hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())

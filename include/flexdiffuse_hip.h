@@ -257,6 +257,13 @@ typedef struct fd_gemm_desc {
      * 160, rows_per_sample %% 32 == 0, trans_ld %% 8 == 0.  0 = off. */
     int32_t trans_n0;
     void* C2;
+    /* (ABI 11, EXPERIMENTAL: measured and left off) in-launch split-K reduction on the ping-pong tiles: sk_sync =
+     * 2 x (output tiles) zero-initialised uint32 (arrival / departure counters, left zero by every launch).  Each K-slice workgroup publishes its
+     * fp32 slab, arrives (agent-scope release), waits for the tile's other slices (acquire, bounded spin) and finishes 1/split_k of the tile's rows
+     * in the fixed slice order -- the bits of the finish launch, without it.  Needs every workgroup of the launch RESIDENT at once
+     * (tiles x split_k <= CUs, one per CU: refused otherwise) and nothing else competing for the CUs: two such launches from two processes
+     * sharing a GPU can starve each other, which is why the product does not use it.  NULL = the finish launch. */
+    void* sk_sync;
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);

@@ -1174,3 +1174,29 @@ def test_transposed_tail_is_refused_outside_its_shapes(dev):
     assert not ops.qkv_merge_supported(200, C, 100)
     with pytest.raises(ValueError, match='trans_n0'):
         ops.gemm_qkv(x, lqkv, 2, 100, ops.ln_row_stats(x))
+
+
+@pytest.mark.parametrize('B,H', [(16, 8), (16, 16)])
+def test_experimental_inlaunch_splitk_reduction_gives_the_finish_launch_bits(dev, B, H):
+    '''fd_gemm_desc.sk_sync (EXPERIMENTAL, ops.SPLITK_INLAUNCH; measured slower than the finish launch and left off: profiles/r06_seam_probe.txt):
+    every K-slice workgroup of a ping-pong split-K launch publishes its slab, arrives on its tile's counter (agent-scope release / acquire, bounded
+    spin) and finishes 1/S of the tile in slice order.  Same bits as the partial pass + k_splitk_finish, with a per-sample bias and a residual;
+    the counters are left re-armed (100 launches in a row).'''
+    from flexdiffuse_amd import ops
+    C = 1280
+    g = torch.Generator().manual_seed(B + H)
+    M = B * H * H
+    x = ops.Act((torch.randn((M, C), generator=g) * 0.7).half().to(dev), B, H, H)
+    cw = ops.prep_conv(torch.randn((C, C, 3, 3), generator=g) * (9 * C) ** -0.5, torch.randn(C, generator=g), dev)
+    kw = dict(bias2=torch.randn((B, C), generator=g).to(dev), ld_bias2=C, residual=torch.randn((M, C), generator=g).half().to(dev))
+    ref = ops.conv2d(x, cw, **kw).t.clone()
+    old = ops.SPLITK_INLAUNCH
+    ops.SPLITK_INLAUNCH = True
+    try:
+        bad = torch.zeros((), dtype=torch.int64, device=dev)
+        for _ in range(100):
+            bad += (ops.conv2d(x, cw, **kw).t != ref).sum()
+        sync = ops._sk_sync[(0, ops.WS_SLOT)]
+        assert int(bad) == 0 and int(sync.abs().sum()) == 0          # ... and it really ran (the counters exist) and left them at zero
+    finally:
+        ops.SPLITK_INLAUNCH = old
