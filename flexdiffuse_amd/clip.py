@@ -46,6 +46,42 @@ def _encoder_forward(layers, h: torch.Tensor, B: int, T: int, heads: int, act: i
     return h
 
 
+class _PlannedEncoder:
+    '''The transformer stack of a tower behind a launch plan (hip.Plan), one per (batch, tokens): ~10 launches per layer x 12 / 24 layers
+    issued by ONE library call instead of ~360 trips through the Python front -- the towers' kernels take 3-4 ms per request, the
+    eager front 5-15 ms of host time depending on the box (profiles/r06_session_ab.txt sec. 8), during which the device idles.  Same
+    kernels, same order, same bits (tests/test_gpu_models.py::test_clip_towers_through_their_launch_plans).  FD_CLIP_PLAN=0: eager.'''
+    MAX_PLANS = 4
+
+    def __init__(self, layers, heads: int, act: int, causal: bool):
+        self.layers, self.heads, self.act, self.causal = layers, heads, act, causal
+        self._plans = {}
+
+    def __call__(self, h: torch.Tensor, B: int, T: int) -> torch.Tensor:
+        import os
+        if os.environ.get('FD_CLIP_PLAN', '1') == '0' or torch.cuda.is_current_stream_capturing():
+            return _encoder_forward(self.layers, h, B, T, self.heads, self.act, self.causal)
+        key = (B, T, h.device.index, hip.stream().value)
+        e = self._plans.get(key)
+        if e is None:
+            _encoder_forward(self.layers, h, B, T, self.heads, self.act, self.causal)     # one-time setup inside the launchers
+            if len(self._plans) >= self.MAX_PLANS:
+                self._plans.pop(next(iter(self._plans)))
+            pool = torch.cuda.MemPool()
+            plan = hip.Plan()
+            with torch.cuda.use_mem_pool(pool, device=h.device):
+                buf = torch.empty_like(h)
+                ops.copy_rows(buf, h)
+                with plan.record():
+                    out = _encoder_forward(self.layers, buf, B, T, self.heads, self.act, self.causal)
+            self._plans[key] = (plan, buf, out, pool)
+            return out.clone()
+        plan, buf, out, _ = e
+        ops.copy_rows(buf, h)
+        plan.replay()
+        return out.clone()        # (the plan's output buffer is rewritten by the next request)
+
+
 def _act_code(name: str) -> int:
     return ops.ACT_QUICK_GELU if name == 'quick_gelu' else ops.ACT_GELU
 
@@ -60,6 +96,7 @@ class _TextModel:
                        for i in range(t.num_hidden_layers)]
         self.fln = (ops.f32(sd['text_model.final_layer_norm.weight'], dev),
                     ops.f32(sd['text_model.final_layer_norm.bias'], dev))
+        self._stack = _PlannedEncoder(self.layers, t.num_attention_heads, _act_code(t.hidden_act), True)
 
     def __call__(self, input_ids: torch.Tensor, **_):
         hip.require_device(input_ids)
@@ -69,8 +106,7 @@ class _TextModel:
         h = torch.empty((B * L, D), dtype=torch.float16, device=ids.device)
         hip.call('fd_embed_tokens_f16', ids.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(),
                  h.data_ptr(), B, L, D, self.cfg.vocab_size, hip.stream())
-        h = _encoder_forward(self.layers, h, B, L, self.cfg.num_attention_heads,
-                             _act_code(self.cfg.hidden_act), True)
+        h = self._stack(h, B, L)
         out = ops.layernorm(h, *self.fln, out_f32=True)
         return (out.view(B, L, D),)
 
@@ -88,6 +124,7 @@ class _VisionModel:
                      ops.f32(sd['vision_model.post_layernorm.bias'], dev))
         self.layers = [_Layer(sd, f'vision_model.encoder.layers.{i}', dev)
                        for i in range(v.num_hidden_layers)]
+        self._stack = _PlannedEncoder(self.layers, v.num_attention_heads, _act_code(v.hidden_act), False)
 
     def embeddings(self, pixel_values: torch.Tensor) -> torch.Tensor:
         '''(B,3,224,224) fp32 -> (B,257,C) fp16: patch conv (im2col + MFMA GEMM), class token,
@@ -114,8 +151,7 @@ class _VisionModel:
 
     def encoder(self, inputs_embeds: torch.Tensor, **_):
         B, T, C = inputs_embeds.shape
-        h = _encoder_forward(self.layers, inputs_embeds.reshape(B * T, C).contiguous(), B, T,
-                             self.cfg.num_attention_heads, _act_code(self.cfg.hidden_act), False)
+        h = self._stack(inputs_embeds.reshape(B * T, C).contiguous(), B, T)
         return (h.view(B, T, C),)
 
 

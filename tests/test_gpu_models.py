@@ -982,6 +982,34 @@ def test_unet_producer_side_groupnorm_equals_separate_launches(sd15, dev):
     assert torch.equal(a, b) and bool(torch.isfinite(a).all())
 
 
+def test_clip_towers_through_their_launch_plans(sd15, dev):
+    '''The transformer stacks of the full-size CLIP ViT-L/14 towers run from launch plans (clip._PlannedEncoder: one library call per
+    tower instead of ~360 trips through the Python front).  First call (records), replays, and the eager front (FD_CLIP_PLAN=0) give
+    the same bits; a replay with other inputs gives other outputs (the plan really re-reads its input buffer).'''
+    sds, pipe, clip, tok, _ = sd15
+    g = torch.Generator().manual_seed(21)
+    ids = [torch.randint(0, 49000, (8, 77), generator=g).to(dev) for _ in range(2)]
+    px = [torch.randn((1, 3, 224, 224), generator=g).to(dev) for _ in range(2)]
+
+    def towers(i):
+        t = clip.text_model(ids[i])[0].clone()
+        vm = clip.vision_model
+        h = vm.post_layernorm(vm.encoder(vm.pre_layrnorm(vm.embeddings(px[i])))[0])
+        return t, clip.visual_projection(h).clone()
+    os.environ['FD_CLIP_PLAN'] = '0'
+    try:
+        want = [towers(0), towers(1)]
+    finally:
+        del os.environ['FD_CLIP_PLAN']
+    clip.text_model._stack._plans.clear()
+    clip.vision_model._stack._plans.clear()
+    got = [towers(0), towers(1), towers(0), towers(1)]          # record, replay with other inputs, replays
+    assert len(clip.text_model._stack._plans) == 1 and len(clip.vision_model._stack._plans) == 1
+    for k, (t, v) in enumerate(got):
+        assert torch.equal(t, want[k % 2][0]) and torch.equal(v, want[k % 2][1]), k
+    assert not torch.equal(got[0][0], got[1][0]) and not torch.equal(got[0][1], got[1][1])
+
+
 def test_launch_plan_full_size_unet_step(sd15, dev):
     """The recorded plan of the full-size SD1.5 UNet (CFG batch 2 x 2 at 64x64 latents: shared CFG
     prefix, in-place skip concats, LayerNorm-fold statistics, split-K deep levels) replays
