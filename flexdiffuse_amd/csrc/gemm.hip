@@ -427,6 +427,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
 
     GEMM_DMA_TILE(kt0, 0);
     if (NS == 3 && kt0 + 1 < nk) GEMM_DMA_TILE(kt0 + 1, 1);
+    // LayerNorm fold fed with the producer's partial sums: this tile's rows are finalised into LDS here, behind the first DMAs (their wait is
+    // the one the loop makes anyway); every barrier of the K loop lies between this write and the epilogue's reads
+    float* const stats_s = bias_s + 4 * BN;
+    const bool ln_lds = (EPI == 5 || EPI == 6 || EPI == 7 || EPI == 13) && __builtin_amdgcn_readfirstlane(g.ln_parts > 1 ? 1 : 0) != 0;
+    if constexpr (EPI == 5 || EPI == 6 || EPI == 7 || EPI == 13) {
+        if (ln_lds) ln_tile_stats_to_lds<BM>(g, m0, tid, stats_s);
+    }
+    const lds_cfloat stats_tile = ln_lds ? (lds_cfloat)stats_s : (lds_cfloat) nullptr;
     if (NS == 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
 #undef GEMM_DMA_TILE
     if constexpr (EPI == 0 || EPI == 7)   // 7: the generic epilogue with the LayerNorm fold compiled in
         gemm_epilogue<BM, BN, TRANS, WM, WN, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
-                                                       b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr, kslice);
+                                                       b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr, kslice, stats_tile);
     else if constexpr (EPI == 8 || EPI == 9) {   // lean + LayerNorm statistics of the written rows; the
         // exchange buffer reuses stage 0 (the 2-stage K loop ends with a barrier: the stages are dead; the 3-stage loop
         // has its barrier at the TOP of an iteration, so the last K-tile may still be read: one more barrier)
@@ -547,10 +555,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
             gt.bias = g.bias ? g.bias + g.tr_n0 : nullptr;
             gt.bias2 = g.bias2 ? g.bias2 + g.tr_n0 : nullptr;
             gemm_epilogue<BM, BN, true, WM, WN, true>(gt, acc, m0, n0 - g.tr_n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
-                                                      b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr, -1);
+                                                      b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr, -1, stats_tile);
         } else {
             gemm_epilogue_fast<MI, NI, FD_ACT_NONE, false, true, true>(
-                g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN));
+                g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN),
+                nullptr, wm * WTM + fr, wn, m0, stats_tile);
         }
     } else if constexpr (EPI == 11 || EPI == 12) {   // lean (+ residual) + GroupNorm partial sums of the tile's output (gn_part_out)
         if constexpr (NS == 3) __syncthreads();
@@ -559,7 +568,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_f16_dma(GemmArgs g, unsig
             reinterpret_cast<float*>(smem), wm * WTM + fr, wn, m0);
     } else
         gemm_epilogue_fast<MI, NI, (EPI == 3 || EPI == 6) ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, true, (EPI == 5 || EPI == 6)>(
-            g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN));
+            g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN),
+            nullptr, wm * WTM + fr, wn, m0, stats_tile);
 #endif
 }
 
@@ -984,7 +994,8 @@ template <int BM, int BN, bool TRANS, bool CONV, int WM = 2, int NS = 2, int WN 
 static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
     g.tiles_m = fd_cdiv(g.M, BM);
     g.tiles_n = fd_cdiv(g.N, BN);
-    const size_t lds = NS * (size_t)(BM + BN) * 128 + 4 * BN * sizeof(float);   // stages + 2 x (bias, bias2 / colsum) tiles
+    // stages + 2 x (bias, bias2 / colsum) tiles + the tile's LayerNorm statistics when they come as partial sums (ln_tile_stats_to_lds)
+    const size_t lds = NS * (size_t)(BM + BN) * 128 + 4 * BN * sizeof(float) + ((EPI == 5 || EPI == 6 || EPI == 7 || EPI == 13) ? BM * 2 * sizeof(float) : 0);
     dim3 grid(g.tiles_m * g.tiles_n, g.split_k, batch);
     // tensor extents for the buffer descriptors of the LDS-DMA loop (must fit 32 bits)
     const unsigned long long a_bytes =
@@ -1005,7 +1016,8 @@ static int launch_mode(GemmArgs& g, int batch, hipStream_t st) {
         const int occ = (BM >= 256 || lds > 80 * 1024) ? 1 : (BM * BN >= 128 * 128) ? 2 : (BM == 128 ? 3 : 4);  // workgroups / CU
         const int slots = 256 * occ;
         const int nkt = (g.K + BK - 1) / BK / g.split_k;
-        const bool persistent = NS == 2 && BN != 320 && EPI != 13 && g.K2 == 0 && !g.phase && !g.ln_stats_out && g.strideBias == 0 && (g_persist_mode == 2 ||
+        // (the persistent loop reads finished LayerNorm statistics only: partial sums run the one-tile kernel)
+        const bool persistent = NS == 2 && BN != 320 && EPI != 13 && g.K2 == 0 && !g.phase && !g.ln_stats_out && g.ln_parts <= 1 && g.strideBias == 0 && (g_persist_mode == 2 ||
                                 (g_persist_mode == 1 && nkt <= 20 && g.tiles_m * g.tiles_n > slots));
         if constexpr (EPI >= 1 && EPI <= 3) {
             // the persistent loop does not stage the per-sample bias: generic epilogue there
@@ -1293,6 +1305,15 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
         g.ln_stats = d->ln_stats;
         g.bias2 = d->ln_colsum;   // one row for every sample: row stride 0
         g.ldb2 = 0;
+        if (d->ln_stats_parts > 0) {
+            // the statistics come as the producer's partial slabs: each tile finalises its rows into LDS (ln_tile_stats_to_lds)
+            FD_CHECK_ARG((d->ln_stats_parts == 2 || d->ln_stats_parts == 4 || d->ln_stats_parts == 8) && d->ln_stats_rows >= d->M && g_use_dma,
+                         FD_ESHAPE, "fd_gemm_f16: ln_stats_parts must be 2, 4 or 8 with ln_stats_rows >= M, on the LDS-DMA path");
+            g.ln_parts = d->ln_stats_parts;
+            g.ln_rows = d->ln_stats_rows;
+            g.ln_inv_n = 1.0f / (float)d->K;
+            g.ln_eps_in = d->ln_fold_eps > 0.f ? d->ln_fold_eps : 1e-5f;
+        }
     }
     if (d->trans_n0 > 0) {
         // transposed tail: one launch for the stacked [q | k | v] projection of a self-attention (see the header)

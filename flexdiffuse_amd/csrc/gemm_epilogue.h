@@ -61,6 +61,10 @@ struct GemmArgs {
     half_t* C2;
     // experimental in-launch split-K reduction (fd_gemm_desc.sk_sync): [tiles] arrival counters, then [tiles] departure counters
     unsigned* sk_sync;
+    // LayerNorm fold fed with the producer's PARTIAL sums (fd_gemm_desc.ln_stats_parts): ln_stats = [ln_parts][ln_rows][2] raw (sum, sum of squares);
+    // each tile finalises its rows into LDS (ln_tile_stats_to_lds) and the epilogues read (rstd, -mean rstd) from there
+    int ln_parts, ln_rows;
+    float ln_inv_n, ln_eps_in;
 };
 
 // Exact-form GELU  x * Phi(x),  Phi(x) = 0.5 * (1 + erf(x / sqrt 2)),  with erf from Abramowitz &
@@ -145,6 +149,44 @@ __device__ __forceinline__ void epi_store16(half_t* p, u32x4 v) {
     else *reinterpret_cast<u32x4*>(p) = v;
 }
 
+typedef const __attribute__((address_space(3))) floatx2* lds_cf2;
+
+// LayerNorm statistics of a tile's rows from the producer's partial slabs (fd_gemm_desc.ln_stats_parts), finalised ONCE per tile into LDS:
+// thread t < BM sums the k partial (sum, sum of squares) of row m0 + t in slab order and writes (rstd, -mean rstd) -- the arithmetic of
+// k_ln_finalize (norm.hip), bit for bit, without the launch.  Called after the tile's first DMAs are issued and before the first barrier of the
+// main loop: the loads ride on the wait the loop makes anyway.  K = compile-time slab count (all loads in flight together).
+template <int K>
+__device__ __forceinline__ void ln_tile_stats_body(const GemmArgs& g, const float* __restrict__ p, float* __restrict__ dst) {
+    floatx2 v[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) v[t] = *reinterpret_cast<const floatx2*>(p + 2 * (size_t)t * g.ln_rows);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {   // fixed order
+        s1 += v[t][0];
+        s2 += v[t][1];
+    }
+    const float mean = s1 * g.ln_inv_n;
+    const float var = fmaxf(fmaf(-mean, mean, s2 * g.ln_inv_n), 0.f);
+    const float rstd = rsqrtf(var + g.ln_eps_in);
+    *reinterpret_cast<floatx2*>(dst) = floatx2{rstd, -mean * rstd};
+}
+
+template <int BM>
+__device__ __forceinline__ void ln_tile_stats_to_lds(const GemmArgs& g, int m0, int tid, float* stats_s) {
+    if (tid < BM) {
+        const int m = min(m0 + tid, g.M - 1);
+        const float* p = g.ln_stats + 2 * (size_t)m;
+        float* dst = stats_s + 2 * tid;
+        switch (g.ln_parts) {
+            case 2: ln_tile_stats_body<2>(g, p, dst); break;
+            case 4: ln_tile_stats_body<4>(g, p, dst); break;
+            default: ln_tile_stats_body<8>(g, p, dst); break;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS writes are done before whatever barrier comes next
+}
+
 // Lean epilogue for the common case: a tile that lies completely inside [M][N], fp16 output with
 // 16-byte-aligned rows, bias / per-sample bias already staged in LDS by the main loop, activation
 // and residual fixed at COMPILE time.  The generic epilogue below handles every flag at run time
@@ -162,7 +204,15 @@ template <int MI, int NI, int ACT, bool RES, bool B2, bool LNF = false, bool STA
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&acc)[MI][NI], int row0,
                                                    int col0, int coll, int fq, int z,
                                                    lds_cfloat bias_tile, lds_cfloat bias2_tile,
-                                                   float* xch = nullptr, int trow0 = 0, int wn = 0, int m0 = 0) {
+                                                   float* xch = nullptr, int trow0 = 0, int wn = 0, int m0 = 0,
+                                                   lds_cfloat stats_tile = nullptr) {
+    // LNF: the rows' (rstd, -mean rstd) from global memory, or -- stats_tile != nullptr (a workgroup-uniform choice) -- from the tile's LDS copy
+    // that ln_tile_stats_to_lds finalised from the producer's partial sums; trow0 = this lane's row inside the tile
+#define LNF_STAT(DST, I)                                                                                   \
+    {                                                                                                      \
+        if (stats_tile) DST = *reinterpret_cast<lds_cf2>(stats_tile + 2 * (trow0 + (I) * 16));             \
+        else DST = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)(row0 + (I) * 16));          \
+    }
     typedef const __attribute__((address_space(3))) floatx4* lds_cf4;
     const int pcol = (fq & 1) * 16 + (fq >> 1) * 8;   // column of this lane's paired 16-byte store
     if constexpr (ACT == FD_ACT_GEGLU) {
@@ -189,14 +239,14 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
         // LNF: (rstd, -mean * rstd) of this lane's row, loaded ONE ROW BLOCK AHEAD: a load issued inside block i is
         // waited for with vmcnt(0), i.e. together with block i-1's stores -- a load and a store round trip per block
         floatx2 st_next = {g.alpha, 0.f};
-        if constexpr (LNF) st_next = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)row0);
+        if constexpr (LNF) LNF_STAT(st_next, 0)
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             half_t* Crow = Cb + (size_t)i * 16 * g.ldc;
             half4 og[NP];
             const floatx2 st = st_next;
             if constexpr (LNF) {
-                if (i + 1 < MI) st_next = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)(row0 + (i + 1) * 16));
+                if (i + 1 < MI) LNF_STAT(st_next, i + 1)
             }
             // two columns per issue slot (packed fp32): st = (rstd, -mean rstd) or (alpha, 0)
             const floatx2 s0 = {st[0], st[0]}, s1 = {st[1], st[1]};
@@ -247,7 +297,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
         if (g.phase) Cb = reinterpret_cast<half_t*>(g.C) + col0;   // rows are mapped per 16-row block below
         const half_t* Rb = RES ? g.res + (size_t)z * g.strideRes + (size_t)row0 * g.ldr + col0 + fq * 4 : nullptr;
         floatx2 st_next = {g.alpha, 0.f};   // LNF: one row block ahead (see the GEGLU branch)
-        if constexpr (LNF) st_next = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)row0);
+        if constexpr (LNF) LNF_STAT(st_next, 0)
         // GNP_WM > 0 (the tile spans the row, N == BN, and lies inside one sample): GroupNorm partial sums of the tile's output per
         // COLUMN PAIR, from the fp16-rounded values, with v_dot2_f32_f16 (a pair never straddles two groups: N / groups is even)
         float gsum[GNP_WM ? NI : 1][2], gsq[GNP_WM ? NI : 1][2];
@@ -273,7 +323,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
             half4 oh[NI];
             const floatx2 st = st_next;
             if constexpr (LNF) {
-                if (i + 1 < MI) st_next = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)(row0 + (i + 1) * 16));
+                if (i + 1 < MI) LNF_STAT(st_next, i + 1)
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j)
@@ -401,12 +451,15 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
     }
 }
 
+#undef LNF_STAT
+
 // Fused epilogue shared by the register-staged and the LDS-DMA main loops.
 template <int BM, int BN, bool TRANS, int WM = 2, int WN = 2, bool LN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                                               floatx4 (&acc)[BM / WM / 16][BN / WN / 16], int m0, int n0,
                                               int wm, int wn, int fr, int fq, int z,
-                                              lds_cfloat bias_tile = nullptr, lds_cfloat bias2_tile = nullptr, int kslice = -1) {
+                                              lds_cfloat bias_tile = nullptr, lds_cfloat bias2_tile = nullptr, int kslice = -1,
+                                              lds_cfloat stats_tile = nullptr) {
     // bias_tile: this tile's bias[n0 .. n0+BN) staged in LDS by the main loop's first DMA group
     // (zeros past N).  A bias read from global memory here is a dependent L2 round trip that
     // every wave of the workgroup sits out between the last MFMA and the first store
@@ -465,8 +518,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     const int mb = min(m0 + wm * WTM + i * 16 + fq * 4, g.M - 4 > 0 ? g.M - 4 : 0);
-                    const floatx4 s01 = *reinterpret_cast<const floatx4*>(g.ln_stats + 2 * (size_t)mb);
-                    const floatx4 s23 = *reinterpret_cast<const floatx4*>(g.ln_stats + 2 * (size_t)mb + 4);
+                    typedef const __attribute__((address_space(3))) floatx4* lds_cf4s;
+                    // (stats_tile: the tile's rows finalised into LDS from the producer's partial sums, ln_tile_stats_to_lds)
+                    floatx4 s01, s23;
+                    if (stats_tile) {
+                        s01 = *reinterpret_cast<lds_cf4s>(stats_tile + 2 * (mb - m0));
+                        s23 = *reinterpret_cast<lds_cf4s>(stats_tile + 2 * (mb - m0) + 4);
+                    } else {
+                        s01 = *reinterpret_cast<const floatx4*>(g.ln_stats + 2 * (size_t)mb);
+                        s23 = *reinterpret_cast<const floatx4*>(g.ln_stats + 2 * (size_t)mb + 4);
+                    }
                     ln_rs[i][0] = s01[0]; ln_mr[i][0] = s01[1]; ln_rs[i][1] = s01[2]; ln_mr[i][1] = s01[3];
                     ln_rs[i][2] = s23[0]; ln_mr[i][2] = s23[1]; ln_rs[i][3] = s23[2]; ln_mr[i][3] = s23[3];
                 }
@@ -565,7 +626,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                     }
                 }
                 if (LN && g.ln_stats) {
-                    const floatx2 st = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)m);
+                    floatx2 st;
+                    if (stats_tile) st = *reinterpret_cast<lds_cf2>(stats_tile + 2 * (m - m0));
+                    else st = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)m);
                     floatx4 cv = {0.f, 0.f, 0.f, 0.f}, cg = {0.f, 0.f, 0.f, 0.f};
                     if (g.bias2 && nb0 + 16 < g.N) {
                         cv = *reinterpret_cast<const floatx4*>(g.bias2 + nb0);
@@ -644,7 +707,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                 else b2v = *reinterpret_cast<const floatx4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
             }
             if (LN && g.ln_stats) {   // LayerNorm fold (see gemm_epilogue_fast): bias2 carries colsum(W')
-                const floatx2 st = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)m);
+                floatx2 st;
+                if (stats_tile) st = *reinterpret_cast<lds_cf2>(stats_tile + 2 * (m - m0));
+                else st = *reinterpret_cast<const floatx2*>(g.ln_stats + 2 * (size_t)m);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[i][j][r], st[0], fmaf(st[1], b2v[r], bsum[r]));
             } else {

@@ -335,6 +335,14 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
     PP_PREP_A(0); PP_ISSUE(0, 0); PP_PREP(1); PP_ISSUE(1, 0); PP_PREP(2); PP_ISSUE(2, 0); PP_PREP(3); PP_ISSUE(3, 0);
     PP_PREP(0); PP_ISSUE(0, 1); PP_PREP(1); PP_ISSUE(1, 1);
     PP_PREP(2);   // phase 0 stages B1 of K-tile 1
+    // LayerNorm fold fed with the producer's partial sums (fd_gemm_desc.ln_stats_parts): the tile's rows finalised into LDS behind the six
+    // prologue pieces; the barriers of the K loop separate this write from the epilogue's reads
+    float* const stats_s = bias_s + 4 * BN;
+    const bool ln_lds = (EPI == 5 || EPI == 6 || EPI == 7) && __builtin_amdgcn_readfirstlane(g.ln_parts > 1 ? 1 : 0) != 0;
+    if constexpr (EPI == 5 || EPI == 6 || EPI == 7) {
+        if (ln_lds) ln_tile_stats_to_lds<BM>(g, m0, tid, stats_s);
+    }
+    const lds_cfloat stats_tile = ln_lds ? (lds_cfloat)stats_s : (lds_cfloat) nullptr;
     PP_WAIT();
     PP_BAR();
     const bool late = wave >= 4;   // the half that runs one barrier behind
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
         }
     } else if constexpr (EPI == 0 || EPI == 7)
         gemm_epilogue<BM, BN, false, WM_, WN_, EPI == 7>(g, acc, m0, n0, wm, wn, fr, fq, z, (g.bias && g.bias_lds) ? (lds_cfloat)bias_s : (lds_cfloat) nullptr,
-                                                         b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr, kslice);
+                                                         b2_staged ? (lds_cfloat)(bias_s + BN) : (lds_cfloat) nullptr, kslice, stats_tile);
     else if constexpr (EPI == 8 || EPI == 9) {
         // the row-statistics exchange buffer reuses the ring: outstanding zero-fill DMAs must have landed before it is written
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -477,7 +485,8 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
             reinterpret_cast<float*>(smem), wm * WTM + fr, wn, m0);
     } else
         gemm_epilogue_fast<MI, NI, (EPI == 3 || EPI == 6) ? FD_ACT_GEGLU : FD_ACT_NONE, EPI == 2, true, (EPI == 5 || EPI == 6)>(
-            g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN));
+            g, acc, m0 + wm * WTM + fr, n0 + wn * WTN, wn * WTN, fq, z, (lds_cfloat)bias_s, (lds_cfloat)(bias_s + BN),
+            nullptr, wm * WTM + fr, wn, m0, stats_tile);
 #ifdef FD_PP_STAMPS
     if (EPI != 10 && g.ws && lane == 0) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(g.ws) + ((size_t)blockIdx.x * 8 + wave) * 16;
@@ -498,7 +507,7 @@ static int pp_launch_k2(GemmArgs& g, int batch, hipStream_t st) {
     constexpr int BM = WM_ * MI * 16, BN = WN_ * NI * 16;
     g.tiles_m = g.M / BM;
     g.tiles_n = g.N / BN;
-    const size_t lds = 2 * (size_t)(BM + BN) * 128 + 4 * BN * sizeof(float);
+    const size_t lds = 2 * (size_t)(BM + BN) * 128 + 4 * BN * sizeof(float) + ((EPI == 5 || EPI == 6 || EPI == 7) ? BM * 2 * sizeof(float) : 0);
     const unsigned long long a_bytes = CONV ? 2ull * (((unsigned long long)(g.M / (g.Ho * g.Wo)) * g.Hi * g.Wi - 1) * g.Cpix + g.Cin)
                                             : 2ull * ((unsigned long long)(g.M - 1) * g.lda + g.K);
     const unsigned long long w_bytes = 2ull * ((unsigned long long)(g.N - 1) * g.ldw + g.K + g.K2);

@@ -37,7 +37,7 @@ class fd_gemm_desc(ctypes.Structure):
                 ('gn_out', c_void_p), ('gn_gamma', c_void_p), ('gn_beta', c_void_p),
                 ('gn_groups', c_int32), ('gn_silu', c_int32), ('gn_eps', c_float), ('gn_skip_c', c_int32),
                 ('gn_part_out', c_void_p), ('gn_part_chunks', c_int32), ('trans_n0', c_int32), ('C2', c_void_p),
-                ('sk_sync', c_void_p)]
+                ('sk_sync', c_void_p), ('ln_stats_parts', c_int32), ('ln_stats_rows', c_int32), ('ln_fold_eps', c_float)]
 
 
 class fd_attention_desc(ctypes.Structure):
@@ -315,6 +315,21 @@ def _inlaunch_request(d: 'fd_gemm_desc', dev: torch.device, tile: int, split: in
     return True
 
 
+LN_PARTS = os.environ.get('FD_UNET_LN_FINALIZE', '0') != '1'    # LayerNorm partial sums finalised by the CONSUMER GEMM's tiles (A/B: FD_UNET_LN_FINALIZE=1 = the finalise launch)
+
+
+def _set_ln_stats(d: 'fd_gemm_desc', ln_stats: torch.Tensor, w: LinW, M: int, eps: float = 1e-5):
+    '''ln_stats [M][2]: finished (rstd, -mean rstd) pairs; [k][M][2] (k in 2, 4, 8): the raw partial sums a producer GEMM wrote through
+    ln_stats_out -- the consumer's tiles finalise their own rows (fd_gemm_desc.ln_stats_parts), no fd_ln_finalize_stats_f32 launch.'''
+    assert w.colsum is not None and ln_stats.dtype == torch.float32 and ln_stats.is_contiguous()
+    if ln_stats.dim() == 3:
+        assert ln_stats.shape[1:] == (M, 2) and ln_stats.shape[0] in (2, 4, 8), tuple(ln_stats.shape)
+        d.ln_stats_parts, d.ln_stats_rows, d.ln_fold_eps = ln_stats.shape[0], M, eps
+    else:
+        assert ln_stats.shape == (M, 2)
+    d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), w.colsum.data_ptr()
+
+
 def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
          bias2: Optional[torch.Tensor] = None, ld_bias2: int = 0, rows_per_sample: int = 0,
          out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0,
@@ -347,8 +362,7 @@ def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[to
         assert a2.shape[0] == M and a2.stride(1) == 1 and a2.dtype == torch.float16
         d.A2, d.lda2, d.K2 = a2.data_ptr(), a2.stride(0), K2
     if ln_stats is not None:      # `a` holds the un-normalised rows, `w` comes from prep_linear_ln
-        assert w.colsum is not None and ln_stats.shape == (M, 2)
-        d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), w.colsum.data_ptr()
+        _set_ln_stats(d, ln_stats, w, M)
     if ln_stats_out is not None:  # the GEMM also writes the LayerNorm statistics of its output rows
         assert ln_stats_out.shape[-2:] == (M, 2) and ln_stats_out.dtype == torch.float32 and ln_stats_out.is_contiguous()
         d.ln_stats_out, d.ln_eps = ln_stats_out.data_ptr(), ln_eps
@@ -381,8 +395,7 @@ def gemm_vt(a: torch.Tensor, w: LinW, B: int, rows_per_sample: int, ld: int,
     d.trans_out, d.trans_ld, d.trans_sample_stride = 1, ld, w.N * ld
     d.alpha, d.batch = 1.0, 1
     if ln_stats is not None:
-        assert w.colsum is not None and ln_stats.shape == (M, 2)
-        d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), w.colsum.data_ptr()
+        _set_ln_stats(d, ln_stats, w, M)
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     return out
 
@@ -401,7 +414,7 @@ def gemm_qkv(a: torch.Tensor, w: LinW, B: int, rows_per_sample: int, ln_stats: t
     The hidden states are read once; same bits as gemm(..., wqk) + gemm_vt(..., wv).'''
     M, K = a.shape
     C = w.N // 3
-    assert w.N == 3 * C and K == w.K and M == B * rows_per_sample and w.colsum is not None and ln_stats.shape == (M, 2)
+    assert w.N == 3 * C and K == w.K and M == B * rows_per_sample and w.colsum is not None
     qk = _empty((M, 2 * C), torch.float16, a)
     vt = _empty((B, C, rows_per_sample), torch.float16, a)
     d = fd_gemm_desc()
@@ -411,7 +424,7 @@ def gemm_qkv(a: torch.Tensor, w: LinW, B: int, rows_per_sample: int, ln_stats: t
     d.lda, d.ldw, d.ldc = a.stride(0), w.w.stride(0), 2 * C
     d.rows_per_sample, d.alpha, d.batch = rows_per_sample, 1.0, 1
     d.trans_n0, d.trans_ld, d.trans_sample_stride = 2 * C, rows_per_sample, C * rows_per_sample
-    d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), w.colsum.data_ptr()
+    _set_ln_stats(d, ln_stats, w, M)
     hip.call('fd_gemm_f16', ctypes.byref(d), hip.stream())
     return qk, vt
 

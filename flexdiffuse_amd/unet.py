@@ -335,12 +335,15 @@ class UNet2DConditionModel():
                 return None
             return torch.empty((rows * batch, 2) if k == 1 else (k, rows * batch, 2), dtype=torch.float32, device=x.t.device)
 
-        def fin(st, hh):
+        def fin(st, hh, parts_ok=False):
             '''(rstd, -mean rstd) of the rows of hh: emitted by its producer, finalised from its partial sums, or
-            from one read-only pass.'''
+            from one read-only pass.  parts_ok: the consumer is an fd_gemm_f16 launch that finalises the partial slabs itself,
+            tile by tile (fd_gemm_desc.ln_stats_parts) -- the slabs are handed over as they are, no finalise launch.'''
             if st is None:
                 return ops.ln_row_stats(hh)
-            return st if st.dim() == 2 else ops.ln_finalize_stats(st, C)
+            if st.dim() == 2 or (parts_ok and ops.LN_PARTS and st.shape[0] in (2, 4, 8)):
+                return st
+            return ops.ln_finalize_stats(st, C)
         if gn_fold:
             wb, bb = ops.gn_fold_linear(x, a.gnf, parts=xn if isinstance(xn, ops.GNParts) else None)
             st = mkst(HW, B)
@@ -349,7 +352,7 @@ class UNet2DConditionModel():
             st = mkst(B * HW)
             h = ops.gemm(h.t, a.proj_in, ln_stats_out=st)
         if a.ln_fold:
-            st = fin(st, h)
+            st = fin(st, h, parts_ok=True)
             if a.qkv1 is not None and ops.qkv_merge_supported(B * HW, C, HW) and self._qkv_level(B * HW):
                 qk, vt = ops.gemm_qkv(h, a.qkv1, B, HW, st)
             else:
@@ -371,7 +374,7 @@ class UNet2DConditionModel():
             o = ops.xattn_q(h, a.q2, fin(st, h), a.ctx_img, HW, L, a.heads, d, n_rep=rep)
         else:
             if a.ln_fold:
-                q2 = ops.gemm(h, a.q2, ln_stats=fin(st, h))
+                q2 = ops.gemm(h, a.q2, ln_stats=fin(st, h, parts_ok=True))
             else:
                 q2 = ops.gemm(ops.layernorm(h, *a.ln[1]), a.q2)
             if rep == 1:
@@ -386,7 +389,8 @@ class UNet2DConditionModel():
         st = mkst(B * HW)
         h = ops.gemm(o, a.o2, residual=h, ln_stats_out=st)
         if a.ln_fold:
-            f = ops.gemm(h, a.ff1, act=ops.ACT_GEGLU, ln_stats=fin(st, h))
+            # (GEGLU at K <= 640 runs the persistent tile, which reads finished statistics only: the finalise launch stays there)
+            f = ops.gemm(h, a.ff1, act=ops.ACT_GEGLU, ln_stats=fin(st, h, parts_ok=C >= 1280))
         else:
             f = ops.gemm(ops.layernorm(h, *a.ln[2]), a.ff1, act=ops.ACT_GEGLU)
         if a.ffp is not None:

@@ -264,6 +264,13 @@ typedef struct fd_gemm_desc {
      * (tiles x split_k <= CUs, one per CU: refused otherwise) and nothing else competing for the CUs: two such launches from two processes
      * sharing a GPU can starve each other, which is why the product does not use it.  NULL = the finish launch. */
     void* sk_sync;
+    /* (ABI 11) LayerNorm fold fed with the producer's PARTIAL sums: ln_stats_parts = k in {2, 4, 8} > 0 makes ln_stats the raw slabs
+     * [k][ln_stats_rows][2] (sum, sum of squares per 160-column tile) that a producer GEMM wrote through ln_stats_out, instead of the finished
+     * (rstd, -mean rstd) pairs: every tile of this launch finalises its own rows into LDS (the arithmetic of fd_ln_finalize_stats_f32, bit for
+     * bit, over K columns with ln_fold_eps) -- the finalise launch between a transformer block's producer and consumer GEMMs inside `unet(...)`
+     * (reference pipeline/guide.py:56-58) disappears.  One-tile LDS-DMA and ping-pong kernels (the persistent form is not used then). 0 = off. */
+    int32_t ln_stats_parts, ln_stats_rows;
+    float ln_fold_eps; /* 0 = 1e-5 */
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);

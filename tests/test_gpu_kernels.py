@@ -1200,3 +1200,50 @@ def test_experimental_inlaunch_splitk_reduction_gives_the_finish_launch_bits(dev
         assert int(bad) == 0 and int(sync.abs().sum()) == 0          # ... and it really ran (the counters exist) and left them at zero
     finally:
         ops.SPLITK_INLAUNCH = old
+
+
+@pytest.mark.parametrize('M,C,HW', [(16384, 640, 1024), (4096, 1280, 256), (1024, 1280, 64), (2304, 640, 576)])
+def test_layernorm_partial_sums_finalised_by_the_consumer_tiles(dev, M, C, HW):
+    '''fd_gemm_desc.ln_stats_parts: the LayerNorm-fold consumers of a wide row (q|k, V^T, the merged q|k|v, the cross-attention's q, GEGLU at
+    K >= 1280) take the producer's k partial slabs as they are -- every tile finalises its own rows into LDS with k_ln_finalize's arithmetic --
+    instead of the finished pairs of a fd_ln_finalize_stats_f32 launch.  Same bits, consumer by consumer; the producer is a real statistics-
+    emitting GEMM (o-projection + residual).'''
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    B = M // HW
+    x = (torch.randn((M, C), generator=g) * 0.8).half().to(dev)
+    res = (torch.randn((M, C), generator=g) * (0.5 + torch.rand((M, 1), generator=g)) + torch.randn((M, 1), generator=g)).half().to(dev)
+    wo = ops.prep_linear(torch.randn((C, C), generator=g) * C ** -0.5, torch.randn(C, generator=g) * 0.1, dev)
+    k = ops.can_emit_row_stats(M, C, C)
+    assert k in (2, 4, 8), k
+    parts = torch.empty((k, M, 2), dtype=torch.float32, device=dev)
+    h = ops.gemm(x, wo, residual=res, ln_stats_out=parts)
+    fin = ops.ln_finalize_stats(parts, C)
+    close(fin, ops.ln_row_stats(h), rtol=2e-3, atol=2e-3)            # the slabs really are this tensor's statistics
+    gamma, beta = 1 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    wqk, wv = torch.randn((2 * C, C), generator=g) * C ** -0.5, torch.randn((C, C), generator=g) * C ** -0.5
+    lqk, lv = ops.prep_linear_ln(wqk, None, gamma, beta, dev), ops.prep_linear_ln(wv, None, gamma, beta, dev)
+    lq = ops.prep_linear_ln(wv * 0.7, None, gamma, beta, dev)
+    lqkv = ops.prep_linear_ln(torch.cat([wqk, wv], 0), None, gamma, beta, dev)
+    consumers = {
+        'q|k': lambda st: ops.gemm(h, lqk, ln_stats=st),
+        'q (cross-attention)': lambda st: ops.gemm(h, lq, ln_stats=st),
+        'V^T': lambda st: ops.gemm_vt(h, lv, B, HW, HW, ln_stats=st),
+    }
+    if ops.qkv_merge_supported(M, C, HW):
+        consumers['q|k|v, transposed tail (q|k)'] = lambda st: ops.gemm_qkv(h, lqkv, B, HW, st)[0]
+        consumers['q|k|v, transposed tail (V^T)'] = lambda st: ops.gemm_qkv(h, lqkv, B, HW, st)[1]
+    if C >= 1280:
+        lff = ops.prep_linear_ln(torch.randn((8 * C, C), generator=g) * C ** -0.5, torch.randn(8 * C, generator=g) * 0.1, gamma, beta, dev, geglu=True)
+        consumers['GEGLU'] = lambda st: ops.gemm(h, lff, act=ops.ACT_GEGLU, ln_stats=st)
+    for name, fn in consumers.items():
+        want = fn(fin).clone()
+        got = fn(parts).clone()
+        assert torch.equal(got, want), (name, float((got.float() - want.float()).abs().max()))
+        bad = torch.zeros((), dtype=torch.int64, device=dev)
+        for _ in range(10):
+            bad += (fn(parts) != want).sum()
+        assert int(bad) == 0, name
+    # ... and against torch: LayerNorm(h) @ Wqk^T
+    xn = F.layer_norm(h.float(), (C,), gamma.to(dev), beta.to(dev), 1e-5)
+    close(consumers['q|k'](parts), xn @ wqk.to(dev).t(), rtol=8e-3, atol=8e-3)

@@ -1035,7 +1035,7 @@ def test_launch_plan_full_size_unet_step(sd15, dev):
         assert pipe.graph_fallback is None
     finally:
         pipe.use_plan, pipe.use_graph = True, True
-    assert n > 250, n
+    assert n > 200, n          # (308 entry-point calls in round 5; 245 after round 6's fusions)
     for a, b, c in zip(got, want, graph):
         assert torch.equal(a, b) and torch.equal(a, c)
     assert not torch.equal(got[0], got[1])
