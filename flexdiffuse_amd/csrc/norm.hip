@@ -293,16 +293,33 @@ __global__ __launch_bounds__(256) void k_gn_fold_linear(const float* __restrict_
                                                         float* __restrict__ bias_out) {
     __shared__ float rstd_s[64], mean_s[64];   // G <= 64
     __shared__ float gsum_s[GNF_ROWS][64];
+    __shared__ double red_s[2][256];           // [stat][sub * G + g]
     extern __shared__ __align__(16) unsigned char gnf_lds[];   // the block's ROUNDED output weights, fp16 [GNF_ROWS][C]
     half_t* wr = reinterpret_cast<half_t*>(gnf_lds);
     const int b = blockIdx.y, tid = threadIdx.x;
-    if (tid < G) {   // the combine of k_gn_apply: partial sums in a fixed order, fp64
+    // the combine of the partial sums, fp64, in a fixed order -- spread over all 256 threads (sub-sums of every nsub-th chunk, then nsub values
+    // per group): with one thread per group walking 16-32 chunks the serial loop of dependent-latency loads was most of this 12-us kernel
+    const int nsub = 256 / G;
+    {
+        const int g = tid % G, sub = tid / G;
+        if (sub < nsub) {
+            double s = 0.0, q = 0.0;
+            const float2* src = reinterpret_cast<const float2*>(part) + ((size_t)b * nchunk_stats) * G + g;
+            for (int k = sub; k < nchunk_stats; k += nsub) {
+                const float2 v = src[(size_t)k * G];
+                s += (double)v.x;
+                q += (double)v.y;
+            }
+            red_s[0][sub * G + g] = s;
+            red_s[1][sub * G + g] = q;
+        }
+    }
+    __syncthreads();
+    if (tid < G) {
         double s = 0.0, q = 0.0;
-        const float2* src = reinterpret_cast<const float2*>(part) + ((size_t)b * nchunk_stats) * G + tid;
-        for (int k = 0; k < nchunk_stats; ++k) {
-            const float2 v = src[(size_t)k * G];
-            s += (double)v.x;
-            q += (double)v.y;
+        for (int u = 0; u < nsub; ++u) {
+            s += red_s[0][u * G + tid];
+            q += red_s[1][u * G + tid];
         }
         const double n = (double)HW * (C / G);
         const double mean = s / n;
