@@ -367,7 +367,9 @@ def test_attention(dev, Nq, Nk, heads, d, causal):
                                                   (2048, 1024, 2, 40, False), (4096, 4096, 1, 40, False),
                                                   (2100, 1030, 2, 48, False), (2048, 1024, 1, 32, True),
                                                   (4096, 77, 8, 40, False), (2100, 64, 2, 48, False), (2304, 200, 2, 40, False),
-                                                  # the exact level-0 self-attention launch (k_attention_w8q2<64,3,true,true>: 12 % of the pass)
+                                                  # head_dim 40 on the 32x32x16 QK^T form (k_attention_w8q2m): causal, ragged queries and keys
+                                                  (2048, 2048, 1, 40, True), (2091, 1093, 3, 40, False), (2500, 2500, 1, 40, True),
+                                                  # the exact level-0 self-attention launch (k_attention_w8q2m: 12 % of the pass)
                                                   (4096, 4096, 8, 40, False)])
 def test_attention_prescaled_q(dev, Nq, Nk, heads, d, causal):
     '''q_prescaled: Q carries head_dim^-0.5 * log2(e); the kernel feeds the running max into
