@@ -1151,298 +1151,6 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8q2m(AttnArgs a) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------
-// k_attention_w8q2m with the two halves of a workgroup in OPPOSITE phases (see the interval comment in the body): the per-tile
-// workgroup barrier of k_attention_w8q2m starts all eight waves on the QK^T MFMAs together and sends them into the softmax VALU
-// together, so a SIMD's matrix pipe and its VALU take turns (the tile loop costs the SUM of its MFMA and VALU cycles on real
-// activations).  Three LDS stages instead of two make the skew safe.  Same arithmetic per query, same results bit for bit.
-__global__ __launch_bounds__(512, 4) void k_attention_w8q2p(AttnArgs a) {   // (HIP: the second bound is waves per SIMD)
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NT = 512;
-    constexpr int DV = 3;
-    constexpr int KSTR = 7 * 16;        // 6 chunks of 8 head-dim columns + 16 B pad: 16 rows x 112 B tile the 64 banks
-    constexpr int VSTR = 10 * 16;
-    constexpr int VROWS = DV * 16;
-    constexpr int KBYTES = 64 * KSTR, VBYTES = VROWS * VSTR;
-    constexpr unsigned OOB = 0x7fffffffu;
-    constexpr int STG = KBYTES + VBYTES;
-    __shared__ __attribute__((aligned(16))) char sKV[3 * STG];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, g = lane >> 4;      // PV / O^T domain
-    const int qi = lane & 31, hb = lane >> 5;     // QK^T / S^T domain
-    const int nqb = (a.Nq + 255) >> 8;
-    const int nwg = gridDim.x;
-    int id = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, slot = id >> 3;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    const int qb = id % nqb, h = (id / nqb) % a.heads, b = id / (nqb * a.heads);
-    const int qblk0 = qb * 256;
-    const int q0 = qblk0 + wave * 32;
-    constexpr int d = 40;
-    const half_t* __restrict__ Qb = a.Q + (size_t)b * a.sQ + h * d;
-    const half_t* Kb = a.K + (size_t)b * a.sK + h * d;
-    const half_t* Vb = a.Vt + (size_t)b * a.sVt + (size_t)h * d * a.ldvt;
-    half_t* __restrict__ Ob = a.O + (size_t)b * a.sO + h * d;
-    const int nk8 = (a.Nk + 7) & ~7;
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)Kb, 0, (unsigned)(((size_t)(a.Nk - 1) * a.ldk + d) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)Vb, 0, (unsigned)(((size_t)(d - 1) * a.ldvt + nk8) * 2), 0x00020000);
-
-    half8 qf[3];
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-        const int q = q0 + qi, d0 = (ks * 2 + hb) * 8;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (q < a.Nq && d0 < d) v = *reinterpret_cast<const u32x4*>(Qb + (size_t)q * a.ldq + d0);
-        qf[ks] = __builtin_bit_cast(half8, v);
-    }
-
-    floatx4 o[2][DV];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int dt = 0; dt < DV; ++dt) o[t][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    float m_used = 0.f;   // running (lazy) max of query qi, base-2 logit units, always an fp16 value
-
-    int ntiles = (a.Nk + 63) >> 6;
-    if (a.causal) {
-        const int qend = min(a.Nq, qblk0 + 256);
-        ntiles = min(ntiles, (qend + 63) >> 6);
-    }
-
-    // K: 64 rows x 5 chunks of 16 B (threads 0..319); V^T: 40 live rows x 8 chunks (threads 0..319), rows 40..47 constant
-    const bool kld = tid < 64 * 5;
-    const int krow = tid / 5, kc = tid - krow * 5;
-    const unsigned kvo = kld ? (unsigned)(krow * a.ldk + kc * 8) * 2u : OOB;
-    const unsigned kst = (unsigned)(krow * KSTR + kc * 16);
-    const int vrow = tid >> 3, vc = tid & 7;
-    const bool vlive = tid < VROWS * 8 && vrow < d;
-    const unsigned vvo = vlive ? (unsigned)(vrow * a.ldvt + vc * 8) * 2u : OOB;
-    // 8 keys of chunk vc = keys 8 cc + {0..3} (k slot row g = cc & 1) and 8 cc + {4..7} (g = 2 + (cc & 1)) of 32-key group vc >> 2
-    const unsigned vst = (unsigned)(KBYTES + vrow * VSTR + ((vc >> 2) * 32 + (vc & 1) * 8 + ((vc >> 1) & 1) * 4) * 2);
-
-    u32x4 rk, rv;
-#define ATT_LOADK(T)                                                                          \
-    if ((T) < ntiles) {                                                                       \
-        const int key0 = (T) * 64;                                                            \
-        if (key0 + 64 <= a.Nk) {                                                              \
-            rk = __builtin_amdgcn_raw_buffer_load_b128(rsK, kvo, key0 * a.ldk * 2, 0);        \
-        } else { /* ragged last tile: rows past the end read zero */                          \
-            const unsigned ko = (kld && key0 + krow < a.Nk) ? kvo + (unsigned)key0 * a.ldk * 2u : OOB; \
-            rk = __builtin_amdgcn_raw_buffer_load_b128(rsK, ko, 0, 0);                        \
-        }                                                                                     \
-    }
-#define ATT_LOADV(T)                                                                          \
-    if ((T) < ntiles) {                                                                       \
-        const int key0 = (T) * 64;                                                            \
-        if (key0 + 64 <= a.Nk) {                                                              \
-            rv = __builtin_amdgcn_raw_buffer_load_b128(rsV, vvo, key0 * 2, 0);                \
-        } else { /* key chunks past the end read zero */                                      \
-            const unsigned vo = (key0 + vc * 8 < nk8) ? vvo + (unsigned)key0 * 2u : OOB;      \
-            rv = __builtin_amdgcn_raw_buffer_load_b128(rsV, vo, 0, 0);                        \
-        }                                                                                     \
-    }
-#define ATT_STOREK(T)                                                                         \
-    if ((T) < ntiles && kld) *reinterpret_cast<u32x4*>(sKV + ((T) % 3) * STG + kst) = rk;
-#define ATT_STOREV(T)                                                                         \
-    if ((T) < ntiles && vlive) {                                                              \
-        char* sb = sKV + ((T) % 3) * STG;                                                     \
-        *reinterpret_cast<u32x2*>(sb + vst) = u32x2{rv[0], rv[1]};                            \
-        *reinterpret_cast<u32x2*>(sb + vst + 32) = u32x2{rv[2], rv[3]};                       \
-    }
-
-    // constants of all three stages: K column 40 = 1.0 (carries -m through QK^T), columns 41..47 = 0;
-    // V^T row 40 = 1.0 (the PV product accumulates the softmax denominator), rows 41..47 = 0
-    if (tid < 192) {
-        char* sb = sKV + (tid >> 6) * STG;
-        *reinterpret_cast<u32x4*>(sb + (tid & 63) * KSTR + 5 * 16) = u32x4{0x00003C00u, 0u, 0u, 0u};
-    }
-    if (tid < VROWS * 8 && !vlive) {
-        const unsigned w = vrow == d ? 0x3C003C00u : 0u;
-#pragma unroll
-        for (int buf = 0; buf < 3; ++buf) {
-            char* sb = sKV + buf * STG;
-            *reinterpret_cast<u32x2*>(sb + vst) = u32x2{w, w};
-            *reinterpret_cast<u32x2*>(sb + vst + 32) = u32x2{w, w};
-        }
-    }
-    // K(0), V^T(0) and K(1) resident before the first interval
-    ATT_LOADK(0); ATT_LOADV(0);
-    ATT_STOREK(0); ATT_STOREV(0);
-    ATT_LOADK(1);
-    ATT_STOREK(1);
-    __syncthreads();
-    const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-    floatx16 s[2];            // S^T of one tile: in the A waves it crosses the interval barrier
-    half8 p[2][2];            // P of one tile: in the B waves it crosses the interval barrier
-    unsigned R[2][4][2];
-    auto qk = [&](const int j) __attribute__((always_inline)) {      // s <- K(j) Q^T - m
-        const char* sK = sKV + ((unsigned)j % 3u) * STG;
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks)
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                const half8 kf = *reinterpret_cast<const half8*>(sK + (kh * 32 + qi) * KSTR + (ks * 2 + hb) * 16);
-                s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s[kh], 0, 0, 0);
-            }
-    };
-    auto sm = [&](const int j) __attribute__((always_inline)) {      // p <- 2^s (lazy max, packed vote), the two 16-query B operands
-        const bool need_mask = (j * 64 + 64 > a.Nk) || a.causal;
-        if (need_mask) {
-            const int q = q0 + qi;
-            int kb = j * 64 + hb * 4;
-            asm volatile("" : "+v"(kb));
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = kb + kh * 32 + (i >> 2) * 8 + (i & 3);
-                    if (key >= a.Nk || (a.causal && key > q)) s[kh][i] = -INFINITY;
-                }
-        }
-        // P = 2^s as packed fp16; R[kh][c][w]: keys kh*32 + 8c + 4hb + 2w + {0, 1} of query qi.  Exponentiated BEFORE the
-        // lazy-max vote: the vote is then a max over 16 packed registers (v_pk_maximum3_f16: four values per instruction,
-        // against two for v_max3_f32 on the fp32 logits), P > 2^LAZY_THR <=> s > LAZY_THR; the rare path redoes the tile's P.
-#define ATT_EXP()                                                                              \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                           \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                          \
-            _Pragma("unroll") for (int w = 0; w < 2; ++w) {                                    \
-                const floatx2 e = {__builtin_amdgcn_exp2f(s[kh][4 * c + 2 * w]), __builtin_amdgcn_exp2f(s[kh][4 * c + 2 * w + 1])}; \
-                R[kh][c][w] = __builtin_bit_cast(unsigned, __builtin_convertvector(e, half2v)); \
-            }
-        bool over = true;      // first tile: the running max is set from its row max
-        if (j != 0) {
-            ATT_EXP();
-            half2v pm = __builtin_bit_cast(half2v, R[0][0][0]);
-#pragma unroll
-            for (int i = 1; i < 16; ++i) pm = __builtin_elementwise_maximum(pm, __builtin_bit_cast(half2v, R[i >> 3][(i >> 1) & 3][i & 1]));
-            pm = __builtin_elementwise_maximum(pm, half2v{pm[1], pm[0]});
-            // P >= 0 (or +inf / NaN): fp16 bit patterns order as integers; 0x5C00 = 2^8 = 2^LAZY_THR
-            static_assert(LAZY_THR == 8.0f, "the packed vote compares against fp16 2^8");
-            over = __builtin_bit_cast(unsigned, pm) > 0x5C005C00u;
-        }
-        if (__any(over)) {
-            // advance the running max to the exact row max (rare after the first tiles)
-            float tmax;
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]));
-#pragma unroll
-            for (int i = 3; i < 15; i += 2)
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[0][i]), "v"(s[0][i + 1]));
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[0][15]), "v"(s[1][0]));
-#pragma unroll
-            for (int i = 1; i < 15; i += 2)
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(s[1][i]), "v"(s[1][i + 1]));
-            asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(tmax), "v"(s[1][15]));
-            const unsigned tu = __float_as_uint(tmax);
-            auto r32 = __builtin_amdgcn_permlane32_swap(tu, tu, false, false);
-            const float tm = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
-            float delta = (j == 0) ? tm : fmaxf(tm, 0.f);
-            if (delta == -INFINITY) delta = 0.f;
-            const float m_new = (float)(half_t)fminf(fmaxf(m_used + delta, -60000.f), 60000.f);
-            delta = m_new - m_used;      // the shift actually applied from the next tile on
-            const float alpha = (j == 0) ? 1.f : __builtin_amdgcn_exp2f(-delta);
-            m_used = m_new;
-            if (hb) qf[2][0] = (half_t)(-m_used);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float at = __shfl(alpha, t * 16 + fr, 64);
-#pragma unroll
-                for (int dt = 0; dt < DV; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[t][dt][r] *= at;
-            }
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s[kh][i] -= delta;
-            ATT_EXP();
-        }
-#undef ATT_EXP
-        // lane rows 1, 3 (queries 16..31) of the even chunk <-> lane rows 0, 2 (queries 0..15) of the odd chunk
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-#pragma unroll
-            for (int c = 0; c < 4; c += 2)
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    auto r = __builtin_amdgcn_permlane16_swap(R[kh][c][w], R[kh][c + 1][w], false, false);
-                    R[kh][c][w] = r[0];
-                    R[kh][c + 1][w] = r[1];
-                }
-            p[0][kh] = __builtin_bit_cast(half8, u32x4{R[kh][0][0], R[kh][0][1], R[kh][2][0], R[kh][2][1]});
-            p[1][kh] = __builtin_bit_cast(half8, u32x4{R[kh][1][0], R[kh][1][1], R[kh][3][0], R[kh][3][1]});
-        }
-    };
-    auto pv = [&](const int j) __attribute__((always_inline)) {      // O^T += V^T(j) P^T
-        const char* sV = sKV + ((unsigned)j % 3u) * STG + KBYTES;
-#pragma unroll
-        for (int kg = 0; kg < 2; ++kg)
-#pragma unroll
-            for (int dt = 0; dt < DV; ++dt) {
-                const half8 vf = *reinterpret_cast<const half8*>(sV + (dt * 16 + fr) * VSTR + (kg * 4 + g) * 16);
-                o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, p[0][kg], o[0][dt], 0, 0, 0);
-                o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, p[1][kg], o[1][dt], 0, 0, 0);
-            }
-    };
-    // Interval j (between two workgroup barriers): every thread fetches K(j+2) and V^T(j+1) at the top and stores them at the bottom;
-    // waves 0..3 (A) run  softmax(j), PV(j), QK^T(j+1)   -- VALU first, matrix pipe second,
-    // waves 4..7 (B) run  PV(j-1), QK^T(j), softmax(j)    -- matrix pipe first, VALU second:
-    // a SIMD holds one A and one B wave of each resident workgroup, so its matrix pipe and its VALU are busy at the same time instead
-    // of all its waves asking for the same pipe in the same phase.  Stage t % 3 holds K(t) (written in interval t-2, read in t-1 by A
-    // and in t by B) and V^T(t) (written in t-1, read in t by A and in t+1 by B); both are overwritten two barriers after their last read.
-    if ((__builtin_amdgcn_readfirstlane(wave) >> 2) == 0) {        // A waves (wave-uniform, scalar branch)
-        qk(0);
-        for (int j = 0; j < ntiles; ++j) {
-            ATT_LOADK(j + 2); ATT_LOADV(j + 1);
-            sm(j);
-            pv(j);
-            if (j + 1 < ntiles) qk(j + 1);
-            ATT_STOREK(j + 2); ATT_STOREV(j + 1);
-            __syncthreads();
-        }
-    } else {                                                        // B waves
-        for (int j = 0; j < ntiles; ++j) {
-            ATT_LOADK(j + 2); ATT_LOADV(j + 1);
-            if (j > 0) pv(j - 1);
-            qk(j);
-            sm(j);
-            ATT_STOREK(j + 2); ATT_STOREV(j + 1);
-            __syncthreads();
-        }
-        pv(ntiles - 1);
-    }
-#undef ATT_LOADK
-#undef ATT_LOADV
-#undef ATT_STOREK
-#undef ATT_STOREV
-
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        // denominator = O^T row 40: fragment 2, lane group g = 2, element 0
-        const float l = __shfl(o[t][2][0], 2 * 16 + fr, 64);
-        const float inv = 1.0f / l;
-        const int q = q0 + t * 16 + fr;
-        if (q < a.Nq) {
-#pragma unroll
-            for (int dt = 0; dt < DV; ++dt) {
-                const int d0 = dt * 16 + g * 4;
-                if (d0 >= d) continue;
-                half4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[t][dt][r] * inv);
-                *reinterpret_cast<half4*>(Ob + (size_t)q * a.ldo + d0) = v;
-            }
-        }
-    }
-#endif
-}
-
-
 extern "C" int fd_attention_f16(const fd_attention_desc* d, void* stream) {
     if (fd_plan_recording() && d) {
         const fd_attention_desc dc_ = *d;
@@ -1493,9 +1201,7 @@ extern "C" int fd_attention_f16(const fd_attention_desc* d, void* stream) {
         dim3 grid2(fd_cdiv(d->n_q, 256) * d->heads * d->batch);
         // FD_ATTN_M32=0: the 16x16x32 QK^T form for head_dim 40 too (A/B)
         static const int m32 = getenv("FD_ATTN_M32") ? atoi(getenv("FD_ATTN_M32")) : 1;
-        if (hd == 40 && pre && m32 == 2) {
-            hipLaunchKernelGGL(k_attention_w8q2p, grid2, dim3(512), 0, st, a);
-        } else if (hd == 40 && pre && m32) {
+        if (hd == 40 && pre && m32) {
             hipLaunchKernelGGL(k_attention_w8q2m, grid2, dim3(512), 0, st, a);
         } else if (hd <= 40) {
             if (pre) hipLaunchKernelGGL((k_attention_w8q2<64, 3, true, true>), grid2, dim3(512), 0, st, a);

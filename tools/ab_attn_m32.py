@@ -1,11 +1,11 @@
-'''Level-0 self-attention (B 16, N 4096, 8 heads x 40, Q pre-scaled): the 32x32x16 QK^T kernels (FD_ATTN_M32=2: k_attention_w8q2p, wave halves in
-opposite phases; 1: k_attention_w8q2m) against the 16x16x32 form (FD_ATTN_M32=0), each arm in its own process, interleaved; then the other shapes the dispatch sends there.
+'''Level-0 self-attention (B 16, N 4096, 8 heads x 40, Q pre-scaled): the 32x32x16 QK^T kernel (k_attention_w8q2m, default) against the 16x16x32
+form (FD_ATTN_M32=0), each arm in its own process, interleaved; then the other shapes the dispatch sends there.
     python tools/ab_attn_m32.py'''
 import sys, os, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if len(sys.argv) == 1:
-    arms = [('2', None), ('1', None), ('0', None)] + [(os.environ.get('AB_VARIANT_ARM', '1'), f) for f in sorted(__import__('glob').glob(os.path.join(ROOT, 'tools/_variants/libfd_m32_*.so')))]
+    arms = [('1', None), ('0', None)] + [(os.environ.get('AB_VARIANT_ARM', '1'), f) for f in sorted(__import__('glob').glob(os.path.join(ROOT, 'tools/_variants/libfd_m32_*.so')))]
     for arm, lib in arms * 3:
         env = dict(os.environ); env['FD_ATTN_M32'] = arm
         if lib: env['FD_LIB_PATH'] = lib
