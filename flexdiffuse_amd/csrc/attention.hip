@@ -905,7 +905,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8q2(AttnArgs a) {
 //    operands; the key order inside each 32-key group that this produces is baked into the LDS
 //    image of V^T (k slot (g, e) <-> key 8 ((g & 1) + 2 (e >> 2)) + 4 (g >> 1) + (e & 3)).
 // Same lazy max, same fused denominator (ones row of V^T), same staging as k_attention_w8q2.
-__global__ __launch_bounds__(512, 2) void k_attention_w8q2m(AttnArgs a) {
+__global__ __launch_bounds__(512, 4) void k_attention_w8q2m(AttnArgs a) {   // (HIP: the second bound is waves per SIMD: <= 128 VGPRs, two workgroups per CU)
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 512;
     constexpr int DV = 3;
