@@ -599,7 +599,7 @@ __global__ __launch_bounds__(512, (DV <= 3 ? ATT_W8_MINW : DQK <= 96 ? 2 : 1)) v
 // unchanged.  ~125 VGPRs (4 waves per SIMD: the kernel is not sensitive to occupancy,
 // tools/ab_attn_occ.py).  Same arithmetic per query as k_attention_w8.
 template <int DQK, int DV, bool PRE, bool ONES>
-__global__ __launch_bounds__(512, 2) void k_attention_w8q2(AttnArgs a) {
+__global__ __launch_bounds__(512, (DV <= 3 ? 2 : 4)) void k_attention_w8q2(AttnArgs a) {   // (second bound = waves per SIMD; DV 4: keep two workgroups per CU)
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KS = DQK / 32;
     constexpr int NT = 512;
@@ -1197,7 +1197,13 @@ extern "C" int fd_attention_f16(const fd_attention_desc* d, void* stream) {
     }
     // also on the short text-context rows (n_k = 77): K / V^T staging per query halves (38.6 -> 36.9 us at 16x4096 queries)
     const int q2_mink = 64;
-    if (hd <= 48 && wide == 2 && q2 && d->n_q >= 2048 && d->n_k >= q2_mink) {
+    // head dims 49..64 (SD2.1: 64): the same two-block kernel with four O^T fragments (FD_ATTN_Q2_64=0: one block per wave, A/B)
+    static const int q2_64 = getenv("FD_ATTN_Q2_64") ? atoi(getenv("FD_ATTN_Q2_64")) : 1;
+    if (hd > 48 && hd <= 64 && wide == 2 && q2 && q2_64 && d->n_q >= 2048 && d->n_k >= 1024) {
+        dim3 grid2(fd_cdiv(d->n_q, 256) * d->heads * d->batch);
+        if (pre) hipLaunchKernelGGL((k_attention_w8q2<64, 4, true, false>), grid2, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_attention_w8q2<64, 4, false, false>), grid2, dim3(512), 0, st, a);
+    } else if (hd <= 48 && wide == 2 && q2 && d->n_q >= 2048 && d->n_k >= q2_mink) {
         dim3 grid2(fd_cdiv(d->n_q, 256) * d->heads * d->batch);
         // FD_ATTN_M32=0: the 16x16x32 QK^T form for head_dim 40 too (A/B)
         static const int m32 = getenv("FD_ATTN_M32") ? atoi(getenv("FD_ATTN_M32")) : 1;

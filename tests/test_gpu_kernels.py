@@ -367,6 +367,8 @@ def test_attention(dev, Nq, Nk, heads, d, causal):
                                                   (2048, 1024, 2, 40, False), (4096, 4096, 1, 40, False),
                                                   (2100, 1030, 2, 48, False), (2048, 1024, 1, 32, True),
                                                   (4096, 77, 8, 40, False), (2100, 64, 2, 48, False), (2304, 200, 2, 40, False),
+                                                  # head_dim 64 with two query blocks per wave (k_attention_w8q2<64,4>: SD2.1 at 768x768)
+                                                  (2304, 2304, 2, 64, False), (2100, 1030, 2, 56, False), (2048, 2048, 1, 64, True),
                                                   # head_dim 40 on the 32x32x16 QK^T form (k_attention_w8q2m): causal, ragged queries and keys
                                                   (2048, 2048, 1, 40, True), (2091, 1093, 3, 40, False), (2500, 2500, 1, 40, True),
                                                   # the exact level-0 self-attention launch (k_attention_w8q2m: 12 % of the pass)
