@@ -34,6 +34,86 @@ extern "C" int fd_nchw_f32_to_nhwc_f16(const float* x, void* y, int B, int C, in
     return FD_OK;
 }
 
+// ---- 3x3 / stride 1 / pad 1 convolution of a NARROW input (<= 4 channels) read from the fp32 NCHW tensor: the UNet's conv_in ---------------
+// (4 latent channels -> 320).  As a GEMM the layer is 0.75 GFLOP behind three memory passes (layout change, explicit im2col with K padded
+// 36 -> 128, a 64x64-tile GEMM) and, under CFG, a fourth that replicates the output for the decoder's skip connection.  Here one workgroup
+// makes one output row of one sample: the 3 x (W + 2) x 4 input strip (fp16, as fd_nchw_f32_to_nhwc_f16 rounds it) in LDS, a thread's
+// 8 output channels' 36 taps in registers as fp16 pairs, v_dot2_f32_f16 products (exact fp16 x fp16, fp32 accumulation -- the MFMA path's
+// arithmetic in another summation order), 16-byte NHWC stores to the output and to its replicas.  HBM-write-bound: 21 MB per copy.
+template <int CPT>   // output channels per thread (8: one 16-byte store)
+__global__ __launch_bounds__(256) void k_conv3x3_narrow(const float* __restrict__ x, const half_t* __restrict__ w, const float* __restrict__ bias,
+                                                        half_t* __restrict__ y, int ldy, half_t* __restrict__ y2, int ldy2, int rep2,
+                                                        int B, int Cin, int H, int W, int Cout, float scale) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char sm_c3[];
+    half_t* xs = reinterpret_cast<half_t*>(sm_c3);          // [3][W + 2][4]
+    const int row = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int WP = W + 2;
+    for (int i = tid; i < 3 * WP * 4; i += 256) {
+        const int ci = i & 3, col = (i >> 2) % WP, r = (i >> 2) / WP;
+        const int yy = row + r - 1, xx = col - 1;
+        float v = 0.f;
+        if (ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W) v = x[((size_t)(b * Cin + ci) * H + yy) * W + xx] * scale;
+        xs[i] = (half_t)v;
+    }
+    const int nchunk = Cout / CPT, npg = 256 / nchunk;       // pixel groups that fit the workgroup
+    const int c = tid % nchunk, pg = tid / nchunk;
+    const bool live = pg < npg;
+    // this thread's weights: CPT channels x 36 taps, (ky, kx, ci) order = the order of a pixel's 3 x 12 strip values
+    half2v wr[CPT][18];
+    float bs[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int co = c * CPT + k;
+        const half2v* src = reinterpret_cast<const half2v*>(w + (size_t)(live ? co : 0) * 36);
+#pragma unroll
+        for (int t = 0; t < 18; ++t) wr[k][t] = src[t];
+        bs[k] = bias ? bias[live ? co : 0] : 0.f;
+    }
+    __syncthreads();
+    if (!live) return;
+    const size_t rowbase = ((size_t)b * H + row) * W;
+    for (int p = pg; p < W; p += npg) {
+        half2v xv[18];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const half2v* src = reinterpret_cast<const half2v*>(xs + ((size_t)r * WP + p) * 4);   // 12 consecutive values: columns p .. p+2, 4 channels
+#pragma unroll
+            for (int t = 0; t < 6; ++t) xv[r * 6 + t] = src[t];
+        }
+        typedef half_t halfN __attribute__((ext_vector_type(CPT)));
+        halfN o;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            float acc = bs[k];
+#pragma unroll
+            for (int t = 0; t < 18; ++t) acc = __builtin_amdgcn_fdot2(xv[t], wr[k][t], acc, false);
+            o[k] = (half_t)acc;
+        }
+        *reinterpret_cast<halfN*>(y + (rowbase + p) * ldy + c * CPT) = o;
+        for (int r = 0; r < rep2; ++r)
+            *reinterpret_cast<halfN*>(y2 + ((size_t)r * B * H * W + rowbase + p) * ldy2 + c * CPT) = o;
+    }
+#endif
+}
+
+extern "C" int fd_conv3x3_narrow_f16(const float* x, const void* w, const float* bias, void* y, int ldy, void* y2, int ldy2, int rep2,
+                                     int B, int Cin, int H, int W, int Cout, float scale, void* stream) {
+    FD_PLAN(fd_conv3x3_narrow_f16(x, w, bias, y, ldy, y2, ldy2, rep2, B, Cin, H, W, Cout, scale, fd_s_));
+    FdProfScope fd_prof_(FD_FAMILY_OTHER, stream, 0.0, fd_tag(1u, __LINE__));
+    FD_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && rep2 >= 0 && (rep2 == 0 || y2), FD_EINVAL, "fd_conv3x3_narrow_f16: args");
+    FD_CHECK_ARG(Cin >= 1 && Cin <= 4 && Cout % 8 == 0 && Cout >= 8 && Cout <= 2048 && 256 / (Cout / 8) >= 1 && W <= 1024 && B <= 65535, FD_ESHAPE,
+                 "fd_conv3x3_narrow_f16: Cin=%d (<= 4), Cout=%d (a multiple of 8, <= 2048), W=%d (<= 1024)", Cin, Cout, W);
+    FD_CHECK_ARG(ldy >= Cout && ldy % 8 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)w % 4 == 0 &&
+                     (rep2 == 0 || (ldy2 >= Cout && ldy2 % 8 == 0 && (uintptr_t)y2 % 16 == 0)), FD_ESHAPE,
+                 "fd_conv3x3_narrow_f16: row strides must be multiples of 8 and >= Cout, outputs 16-byte aligned");
+    const size_t lds = (size_t)3 * (W + 2) * 4 * sizeof(half_t);
+    hipLaunchKernelGGL((k_conv3x3_narrow<8>), dim3(H, B), dim3(256), lds, (hipStream_t)stream, x, (const half_t*)w, bias, (half_t*)y, ldy,
+                       (half_t*)y2, ldy2, rep2, B, Cin, H, W, Cout, scale);
+    FD_CHECK_LAUNCH("k_conv3x3_narrow");
+    return FD_OK;
+}
+
 // ---- NHWC fp32 [B][HW][ld] -> NCHW fp32 [B][C][HW]: y = clamp(x*a + b) -------------------
 __global__ void k_nhwc_to_nchw(const float* __restrict__ x, float* __restrict__ y, int B, int C,
                                int HW, int ld, float a, float bofs, int clamp01) {

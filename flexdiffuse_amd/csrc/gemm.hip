@@ -1289,6 +1289,13 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
                      "fd_gemm_f16: ldc must be a multiple of 4");
     if (g.bias) FD_CHECK_ARG((uintptr_t)g.bias % 16 == 0, FD_ESHAPE, "fd_gemm_f16: bias align");
     if (g.res) FD_CHECK_ARG(d->ldr % 4 == 0, FD_ESHAPE, "fd_gemm_f16: ldr must be a multiple of 4");
+    if (d->residual_rows) {
+        FD_CHECK_ARG(d->residual_rows > 0 && g.res && !d->conv && batch == 1 && !d->trans_out && g.M % d->residual_rows == 0 &&
+                         d->residual_rows % 32 == 0, FD_ESHAPE,
+                     "fd_gemm_f16: residual_rows=%d needs a residual, a linear GEMM, batch 1 and M=%d a multiple of it (itself a multiple of 32)",
+                     d->residual_rows, g.M);
+        g.res_rows = d->residual_rows;
+    }
 
     if (d->ln_stats) {
         // LayerNorm fold: C = act(rstd_m (A W'^T)[m][n] - rstd_m mean_m colsum_n + bias_n), W' = W diag(gamma)
@@ -1641,6 +1648,12 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
         FD_CHECK_ARG(bm && g.M % bm == 0 && g.N % bn == 0 && best_split == 1, FD_ESHAPE,
                      "fd_gemm_f16: upsample2x == 2: tile %d / split %d cannot run M=%d N=%d through the lean epilogue",
                      best_tile, best_split, g.M, g.N);
+    }
+    if (g.res_rows) {
+        // the lean epilogues wrap the residual row once per wave row block: a tile must not straddle the wrap; the finish pass of a split launch does not wrap
+        const int bm = best_tile == 23 ? 288 : 256;
+        FD_CHECK_ARG(best_split == 1 && g.res_rows % bm == 0, FD_ESHAPE,
+                     "fd_gemm_f16: residual_rows=%d with tile %d / split_k %d (needs split_k 1 and a multiple of %d rows)", g.res_rows, best_tile, best_split, bm);
     }
     if (best_split > 1)
         FD_CHECK_ARG(!geglu && batch == 1 && g.N % 4 == 0 && g.ws &&

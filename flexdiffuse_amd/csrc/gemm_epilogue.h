@@ -65,6 +65,7 @@ struct GemmArgs {
     // each tile finalises its rows into LDS (ln_tile_stats_to_lds) and the epilogues read (rstd, -mean rstd) from there
     int ln_parts, ln_rows;
     float ln_inv_n, ln_eps_in;
+    int res_rows;   // > 0: the residual row of output row m is m % res_rows (fd_gemm_desc.residual_rows; a multiple of the tile's rows)
 };
 
 // Exact-form GELU  x * Phi(x),  Phi(x) = 0.5 * (1 + erf(x / sqrt 2)),  with erf from Abramowitz &
@@ -295,7 +296,9 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmArgs& g, floatx4 (&
         }
         half_t* Cb = reinterpret_cast<half_t*>(g.C) + (size_t)z * g.strideC + (size_t)row0 * g.ldc + col0;
         if (g.phase) Cb = reinterpret_cast<half_t*>(g.C) + col0;   // rows are mapped per 16-row block below
-        const half_t* Rb = RES ? g.res + (size_t)z * g.strideRes + (size_t)row0 * g.ldr + col0 + fq * 4 : nullptr;
+        // (res_rows: a multiple of the tile's rows, so one wrap of the wave's first row serves its whole row block)
+        const int rrow0 = (RES && g.res_rows) ? row0 % g.res_rows : row0;
+        const half_t* Rb = RES ? g.res + (size_t)z * g.strideRes + (size_t)rrow0 * g.ldr + col0 + fq * 4 : nullptr;
         floatx2 st_next = {g.alpha, 0.f};   // LNF: one row block ahead (see the GEGLU branch)
         if constexpr (LNF) LNF_STAT(st_next, 0)
         // GNP_WM > 0 (the tile spans the row, N == BN, and lies inside one sample): GroupNorm partial sums of the tile's output per
@@ -683,7 +686,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
                 rb2[j] = floatx4{0.f, 0.f, 0.f, 0.f};
                 if (nb0 >= g.N) continue;
                 if (g.res)
-                    rres[j] = *reinterpret_cast<const half4*>(g.res + (size_t)z * g.strideRes + (size_t)m * g.ldr + nb0);
+                    rres[j] = *reinterpret_cast<const half4*>(g.res + (size_t)z * g.strideRes + (size_t)(g.res_rows ? m % g.res_rows : m) * g.ldr + nb0);
                 if (b2_global) rb2[j] = *reinterpret_cast<const floatx4*>(g.bias2 + (size_t)b * g.ldb2 + nb0);
             }
         }
@@ -722,7 +725,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g,
             if (g.res) {
                 half4 rr;
                 if constexpr (BATCH) rr = rres[j];
-                else rr = *reinterpret_cast<const half4*>(g.res + (size_t)z * g.strideRes + (size_t)m * g.ldr + nb0);
+                else rr = *reinterpret_cast<const half4*>(g.res + (size_t)z * g.strideRes + (size_t)(g.res_rows ? m % g.res_rows : m) * g.ldr + nb0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
             }

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(512) void k_gemm_f16_pp(GemmArgs g, unsigned a_byte
                 if (g.bias2) b2 = *reinterpret_cast<const float4*>(g.bias2 + (size_t)(m / g.rows_per_batch) * g.ldb2 + n);
                 float v[4] = {fmaf(a.x, g.alpha, bb.x + b2.x), fmaf(a.y, g.alpha, bb.y + b2.y), fmaf(a.z, g.alpha, bb.z + b2.z), fmaf(a.w, g.alpha, bb.w + b2.w)};
                 if (g.res) {
-                    const half4 rr = *reinterpret_cast<const half4*>(g.res + (size_t)m * g.ldr + n);
+                    const half4 rr = *reinterpret_cast<const half4*>(g.res + (size_t)(g.res_rows ? m % g.res_rows : m) * g.ldr + n);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] += (float)rr[k];
                 }

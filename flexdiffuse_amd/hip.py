@@ -67,6 +67,7 @@ _SIGNATURES = {
     'fd_nchw_f32_to_nhwc_f16': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'fd_nhwc_f32_to_nchw_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P]),
     'fd_im2col_f16': (c_int, [P, P] + [c_int] * 12 + [P]),
+    'fd_conv3x3_narrow_f16': (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'fd_concat_channels_f16': (c_int, [P, P, P, c_int64, c_int, c_int, P]),
     'fd_cfg_ddim_step_f32': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                      c_float, c_float, c_float, c_int, c_int, P]),
@@ -87,7 +88,7 @@ _SIGNATURES = {
     'fd_cast_f16_to_f32': (c_int, [P, P, c_int64, P]),
 }
 
-ABI_VERSION = 11  # FD_ABI_VERSION in include/flexdiffuse_hip.h
+ABI_VERSION = 12  # FD_ABI_VERSION in include/flexdiffuse_hip.h
 _lib: Optional[ctypes.CDLL] = None
 
 

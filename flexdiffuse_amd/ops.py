@@ -37,7 +37,8 @@ class fd_gemm_desc(ctypes.Structure):
                 ('gn_out', c_void_p), ('gn_gamma', c_void_p), ('gn_beta', c_void_p),
                 ('gn_groups', c_int32), ('gn_silu', c_int32), ('gn_eps', c_float), ('gn_skip_c', c_int32),
                 ('gn_part_out', c_void_p), ('gn_part_chunks', c_int32), ('trans_n0', c_int32), ('C2', c_void_p),
-                ('sk_sync', c_void_p), ('ln_stats_parts', c_int32), ('ln_stats_rows', c_int32), ('ln_fold_eps', c_float)]
+                ('sk_sync', c_void_p), ('ln_stats_parts', c_int32), ('ln_stats_rows', c_int32), ('ln_fold_eps', c_float),
+                ('residual_rows', c_int32)]
 
 
 class fd_attention_desc(ctypes.Structure):
@@ -169,6 +170,45 @@ def prep_conv(w: torch.Tensor, b: Optional[torch.Tensor], dev, cin_pad: int = 0)
     wd = torch.zeros((cout, kpad), dtype=torch.float16, device=dev)
     wd[:, :k] = wp.reshape(cout, k).to(dev, torch.float16)
     return ConvW(wd, _bias(b, dev), cout, cin_eff, kh, kw, im2col, kpad)
+
+
+@dataclass
+class NarrowConvW:
+    w: torch.Tensor               # [Cout][3][3][4] fp16 (input channels >= Cin zero)
+    bias: Optional[torch.Tensor]
+    cout: int
+    cin: int
+
+
+# FD_UNET_CONV_IN=0: the UNet's conv_in through layout change + explicit im2col + GEMM (+ the fan-out copy) instead of fd_conv3x3_narrow_f16 (A/B)
+CONV_IN_DIRECT = os.environ.get('FD_UNET_CONV_IN', '1') != '0'
+
+
+def prep_conv_narrow(w: torch.Tensor, b: Optional[torch.Tensor], dev) -> Optional[NarrowConvW]:
+    '''[Cout][Cin <= 4][3][3] -> the operand of fd_conv3x3_narrow_f16 (None when the layer has another shape).'''
+    cout, cin, kh, kw = w.shape
+    if (kh, kw) != (3, 3) or cin > 4 or cout % 8 or cout > 2048:
+        return None
+    wp = torch.zeros((cout, 3, 3, 4), dtype=torch.float32)
+    wp[..., :cin] = w.permute(0, 2, 3, 1).float()
+    return NarrowConvW(wp.to(dev, torch.float16).contiguous(), _bias(b, dev), cout, cin)
+
+
+def conv3x3_narrow(x: torch.Tensor, w: NarrowConvW, out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
+                   rep2: int = 0, scale: float = 1.0) -> Act:
+    '''fp32 (B, Cin <= 4, H, W) -> 3x3 / stride 1 / pad 1 convolution as an fp16 NHWC Act in ONE launch (fd_conv3x3_narrow_f16);
+    `out2` [rep2 * B*H*W][Cout] (row stride free) also receives `rep2` replicas of the output.'''
+    B, C, H, W = x.shape
+    assert C == w.cin and x.dtype == torch.float32
+    x = x.contiguous()
+    if out is None:
+        out = _empty((B * H * W, w.cout), torch.float16, x)
+    assert out.shape == (B * H * W, w.cout) and out.stride(1) == 1 and out.dtype == torch.float16
+    if rep2:
+        assert out2 is not None and out2.shape == (rep2 * B * H * W, w.cout) and out2.stride(1) == 1 and out2.dtype == torch.float16
+    hip.call('fd_conv3x3_narrow_f16', x.data_ptr(), w.w.data_ptr(), _p(w.bias), out.data_ptr(), out.stride(0),
+             _p(out2) if rep2 else None, out2.stride(0) if rep2 else 0, rep2, B, C, H, W, w.cout, scale, hip.stream())
+    return Act(out, B, H, W)
 
 
 def prep_conv_shortcut(w: torch.Tensor, b: Optional[torch.Tensor], ws: torch.Tensor, bs: Optional[torch.Tensor],
@@ -354,6 +394,10 @@ def gemm(a: torch.Tensor, w: LinW, *, act: int = ACT_NONE, residual: Optional[to
     d.M, d.N, d.K = M, w.N, K
     d.lda, d.ldw, d.ldc = a.stride(0), w.w.stride(0), out.stride(0)
     d.ldr = residual.stride(0) if residual is not None else 0
+    if residual is not None and residual.shape[0] != M:
+        # the residual of replicated rows (the CFG fan-out of a shared prefix): row m adds residual row m % rows (fd_gemm_desc.residual_rows)
+        assert M % residual.shape[0] == 0, (M, residual.shape)
+        d.residual_rows = residual.shape[0]
     d.ld_bias2 = ld_bias2
     d.rows_per_sample = rows_per_sample
     d.act, d.out_f32, d.alpha = act, int(out_f32), alpha
@@ -819,6 +863,16 @@ def contiguous_rows(x: torch.Tensor) -> torch.Tensor:
     if x.is_contiguous():
         return x
     return copy_rows(_empty(tuple(x.shape), torch.float16, x), x)
+
+
+# FD_UNET_RES_WRAP=0: the CFG fan-out materialises the residuals' replicas (fd_repeat_rows_f16) instead of wrapping the residual rows (A/B)
+RES_WRAP = os.environ.get('FD_UNET_RES_WRAP', '1') != '0'
+
+
+def residual_wrap_supported(rows: int, rep: int) -> bool:
+    '''True when fd_gemm_f16 can add a residual of `rows` rows to `rep * rows` output rows modulo `rows` (fd_gemm_desc.residual_rows) whatever tile
+    the rule picks: the wrap must fall on a tile boundary -- 256 rows covers every tile but the 288-row one, which needs full tiles of M.'''
+    return RES_WRAP and rep > 1 and rows % 256 == 0 and (rows % 288 == 0 or (rep * rows) % 288 != 0)
 
 
 def repeat_rows(x: torch.Tensor, rep: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

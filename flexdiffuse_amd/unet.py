@@ -139,6 +139,7 @@ class UNet2DConditionModel():
         heads = dict(zip(ch, cfg.num_heads))
         self.G = cfg.norm_num_groups
         self.conv_in = ops.prep_conv(sd['conv_in.weight'], sd['conv_in.bias'], dev, cin_pad=8)
+        self.conv_in_nw = ops.prep_conv_narrow(sd['conv_in.weight'], sd['conv_in.bias'], dev)    # the one-launch form (fd_conv3x3_narrow_f16)
         self.t1 = ops.prep_linear(sd['time_embedding.linear_1.weight'], sd['time_embedding.linear_1.bias'], dev)
         self.t2 = ops.prep_linear(sd['time_embedding.linear_2.weight'], sd['time_embedding.linear_2.bias'], dev)
         temb_w, temb_b = [], []
@@ -385,7 +386,11 @@ class UNet2DConditionModel():
                     ops.attention(q2, kc[r * B * L:(r + 1) * B * L], vtc[r * B:(r + 1) * B], B, a.heads,
                                   HW, L, d, q_prescaled=a.q_pre, out=o[r * B * HW:(r + 1) * B * HW])
         if rep > 1:
-            h, xt, B = ops.repeat_rows(h, rep), ops.repeat_rows(xt, rep), rep * B
+            # the fan-out of the shared prefix: h and the block input are only RESIDUALS from here on (of the out-projection and of the
+            # block's last GEMM), which can read them modulo the prefix's rows (fd_gemm_desc.residual_rows) -- no replicas in HBM
+            if not ops.residual_wrap_supported(B * HW, rep):
+                h, xt = ops.repeat_rows(h, rep), ops.repeat_rows(xt, rep)
+            B = rep * B
         st = mkst(B * HW)
         h = ops.gemm(o, a.o2, residual=h, ln_stats_out=st)
         if a.ln_fold:
@@ -441,8 +446,11 @@ class UNet2DConditionModel():
         # cross-attention (conv_in, the first ResBlock, the first block's self-attention) is
         # computed once on B samples and fanned out there (bit-identical per sample).
         share = rep > 1 and (temb is not None or not isinstance(timestep, torch.Tensor) or timestep.numel() == 1)
-        x = ops.nchw_to_nhwc(sample, rep=1 if share else rep, c_pad=self.conv_in.cin)
-        Be = x.B * (rep if share else 1)
+        # conv_in straight from the fp32 NCHW latents (one launch, replicas of the skip tensor included) where the layer has the shape for it
+        direct = ops.CONV_IN_DIRECT and self.conv_in_nw is not None and (share or rep == 1) and sample.shape[3] <= 1024
+        x = None if direct else ops.nchw_to_nhwc(sample, rep=1 if share else rep, c_pad=self.conv_in.cin)
+        xB, xH, xW = (sample.shape[0], sample.shape[2], sample.shape[3]) if direct else (x.B, x.H, x.W)
+        Be = xB * (rep if share else 1)
         if ctx.shape[0] != Be:
             raise ValueError(f'encoder_hidden_states batch {ctx.shape[0]} != latent batch {Be}')
         if temb is None:
@@ -471,9 +479,15 @@ class UNet2DConditionModel():
                 return skips[-1][1][:, :c]
             return None
 
-        HW = x.H * x.W
+        HW = xH * xW
         buf, view, ch = slot(Be * HW, self.conv_in.cout)
-        if fan > 1:
+        if direct and fan > 1:
+            rep_out = view if view is not None else torch.empty((Be * HW, self.conv_in.cout), dtype=torch.float16, device=self.device)
+            h = ops.conv3x3_narrow(sample.to(torch.float32), self.conv_in_nw, out2=rep_out, rep2=fan)
+            push(Act(rep_out, Be, xH, xW), buf if view is not None else None, ch if view is not None else None)
+        elif direct:
+            h = push(ops.conv3x3_narrow(sample.to(torch.float32), self.conv_in_nw, out=view), buf, ch)
+        elif fan > 1:
             h = ops.conv2d(x, self.conv_in)
             if view is None:
                 push(Act(ops.repeat_rows(h.t, fan), Be, h.H, h.W), None, None)

@@ -32,7 +32,7 @@ extern "C" {
 #define FD_ESHAPE (-2) /* unsupported shape / alignment */
 #define FD_EHIP (-3)   /* HIP runtime error */
 
-#define FD_ABI_VERSION 11
+#define FD_ABI_VERSION 12
 
 int fd_abi_version(void);
 const char* fd_last_error(void);
@@ -271,6 +271,11 @@ typedef struct fd_gemm_desc {
      * (reference pipeline/guide.py:56-58) disappears.  One-tile LDS-DMA and ping-pong kernels (the persistent form is not used then). 0 = off. */
     int32_t ln_stats_parts, ln_stats_rows;
     float ln_fold_eps; /* 0 = 1e-5 */
+    /* (ABI 12) residual_rows > 0: output row m adds residual row m %% residual_rows -- the residual of a GEMM whose rows are `rep` replicas of
+     * a shared prefix (the classifier-free-guidance fan-out inside `unet(...)`, reference pipeline/guide.py:56-58: both halves of the batch read
+     * the same hidden states until the first cross-attention) without materialising the replicas.  Linear GEMM, batch 1, split_k 1,
+     * M %% residual_rows == 0 and residual_rows a multiple of the tile's rows (256 covers every tile but the 288-row one).  0 = row m. */
+    int32_t residual_rows;
 } fd_gemm_desc;
 
 int fd_gemm_f16(const fd_gemm_desc* desc, void* stream);
@@ -397,6 +402,14 @@ int fd_nchw_f32_to_nhwc_f16(const float* x, void* y, int B, int C, int HW, int r
 int fd_nhwc_f32_to_nchw_f32(const float* x, float* y, int B, int C, int HW, int ld, float a,
                             float b, int clamp01, void* stream);
 /* im2col for convolutions with fewer than 64 input channels; out [B*Ho*Wo][k_pad]. */
+/* (ABI 12) 3x3 / stride 1 / pad 1 convolution of a NARROW input (Cin <= 4) read straight from the fp32 NCHW tensor -- the UNet's conv_in
+ * (reference pipeline/guide.py:56-58, the first layer of `unet(...)`; diffusers UNet2DConditionModel.conv_in):
+ *   y[(b H + i) W + j][co] = bias[co] + sum_{ky, kx, ci} half(x[b][ci][i + ky - 1][j + kx - 1] * scale) * w[co][ky][kx][ci]
+ * (fp16 x fp16 products, fp32 accumulation, fp16 NHWC rows of stride ldy).  w: [Cout][3][3][4] fp16, channels >= Cin zero.  rep2 > 0 also
+ * writes `rep2` replicas of the output to y2 (row stride ldy2, replica r at rows r B H W ...): the classifier-free-guidance fan-out's copy
+ * of the first skip tensor.  One launch instead of fd_nchw_f32_to_nhwc_f16 + fd_im2col_f16 + fd_gemm_f16 (+ fd_repeat_rows_f16). */
+int fd_conv3x3_narrow_f16(const float* x, const void* w, const float* bias, void* y, int ldy, void* y2, int ldy2, int rep2,
+                          int B, int Cin, int H, int W, int Cout, float scale, void* stream);
 int fd_im2col_f16(const void* x, void* y, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int KH,
                   int KW, int stride, int pad_t, int pad_l, int k_pad, void* stream);
 int fd_concat_channels_f16(const void* a, const void* b, void* out, int64_t M, int Ca, int Cb,

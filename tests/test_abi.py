@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
 def test_ctypes_table_matches_header():
     from flexdiffuse_amd import hip
     assert sorted(hip.declared_symbols()) == declared_in_header()
-    assert hip.lib().fd_abi_version() == hip.ABI_VERSION == 11
+    assert hip.lib().fd_abi_version() == hip.ABI_VERSION == 12
 
 
 def test_struct_layouts_match_header():

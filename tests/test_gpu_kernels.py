@@ -1119,6 +1119,37 @@ def test_groupnorm_partial_sums_are_refused_where_no_tile_spans_the_row(dev):
         ops.FORCE_TILE = old
 
 
+@pytest.mark.parametrize('B,Cin,H,W,Cout,rep2', [(8, 4, 64, 64, 320, 2), (2, 4, 96, 96, 320, 0), (1, 3, 17, 23, 64, 3), (2, 4, 8, 8, 1280, 2)])
+def test_conv3x3_narrow_input_in_one_launch(dev, B, Cin, H, W, Cout, rep2):
+    '''fd_conv3x3_narrow_f16 (the UNet's conv_in: 4 latent channels -> 320 from the fp32 NCHW latents, replicas of the output for the CFG
+    fan-out included) against the three launches it replaces (layout change, explicit im2col, GEMM: the same fp16 products in another
+    summation order -> within fp16 rounding of each other) and against torch's fp32 convolution; ragged widths, borders, a column-slice
+    destination; repeats bit for bit.'''
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + Cout)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) * (9 * Cin) ** -0.5
+    b = torch.randn(Cout, generator=g)
+    nw = ops.prep_conv_narrow(w, b, dev)
+    assert nw is not None and ops.prep_conv_narrow(torch.zeros((64, 8, 3, 3)), None, dev) is None
+    xd = x.to(dev)
+    M = B * H * W
+    buf = torch.full((max(rep2, 1) * M, Cout + 64), 3.0, dtype=torch.float16, device=dev)
+    view = buf[:, 64:]
+    got = ops.conv3x3_narrow(xd, nw, out2=view if rep2 else None, rep2=rep2, scale=0.5)
+    again = ops.conv3x3_narrow(xd, nw, scale=0.5)
+    assert torch.equal(got.t, again.t) and bool(torch.isfinite(got.t.float()).all())
+    if rep2:
+        assert torch.equal(view, torch.cat([got.t] * rep2, 0)) and bool((buf[:, :64] == 3.0).all())
+    old = ops.conv2d(ops.nchw_to_nhwc(xd, c_pad=8, scale=0.5), ops.prep_conv(w, b, dev, cin_pad=8))
+    d = (got.t.float() - old.t.float()).abs()
+    assert float(d.max()) <= 2.0 ** -9 * max(1.0, float(old.t.float().abs().max())), float(d.max())
+    ref = torch.nn.functional.conv2d((x * 0.5).half().float(), w.half().float(), b, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    close(got.t.float().cpu(), ref, rtol=2e-3, atol=2e-3)
+    with pytest.raises(ValueError):
+        ops.conv3x3_narrow(xd, nw, out=torch.empty((M, Cout + 4), dtype=torch.float16, device=dev)[:, :Cout])     # row stride not a multiple of 8
+
+
 def test_repeat_rows_is_one_launch_and_equals_the_copies(dev):
     '''fd_repeat_rows_f16: the CFG fan-out (B samples -> rep * B) as one launch, into a contiguous tensor or into a column slice of a wider
     buffer (the skip tensors' concat buffers); equals rep separate fd_copy2d_f16 calls.'''
@@ -1135,6 +1166,46 @@ def test_repeat_rows_is_one_launch_and_equals_the_copies(dev):
         assert torch.equal(buf[:, 320:], torch.cat([x, x], 0)) and bool((buf[:, :320] == 7.0).all())
     with pytest.raises(ValueError):
         ops.repeat_rows(x[:, :36], 2)                  # 36 columns: not a multiple of 8
+
+
+@pytest.mark.parametrize('M,rows,N,K,K2,stats', [(65536, 32768, 320, 320, 0, True),     # the out-projection behind the CFG fan-out (256x320 tile, statistics epilogue)
+                                                  (65536, 32768, 320, 1280, 320, False),  # FF-out + folded proj_out, appended operand (ping-pong tile)
+                                                  (4096, 1024, 320, 320, 0, False), (2048, 512, 1280, 640, 0, False), (1536, 768, 640, 320, 0, True),
+                                                  (3072, 1024, 200, 96, 0, False)])        # generic epilogue (ragged N)
+def test_gemm_residual_read_modulo_a_row_count(dev, M, rows, N, K, K2, stats):
+    '''fd_gemm_desc.residual_rows (ops.gemm with a residual of fewer rows): output row m adds residual row m % rows -- the residual of the
+    replicated rows of a shared prefix without the replicas.  Same bits as the GEMM fed with the materialised replicas, on the lean
+    statistics epilogue, the ping-pong tile with an appended operand, small tiles and the generic epilogue.'''
+    from flexdiffuse_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn((M, K), generator=g).half().to(dev)
+    a2 = torch.randn((M, K2), generator=g).half().to(dev) if K2 else None
+    w = ops.prep_linear(torch.randn((N, K + K2), generator=g) * (K + K2) ** -0.5, torch.randn(N, generator=g), dev)
+    res = torch.randn((rows, N), generator=g).half().to(dev)
+    full = ops.repeat_rows(res, M // rows) if N % 8 == 0 else torch.cat([res] * (M // rows), 0)
+    kw = {}
+    if stats and ops.can_emit_row_stats(M, N, K, N, N) == 1:
+        kw = dict(ln_stats_out=torch.zeros((M, 2), dtype=torch.float32, device=dev))
+    got = ops.gemm(a, w, a2=a2, residual=res, **kw).clone()
+    st_got = kw['ln_stats_out'].clone() if kw else None
+    want = ops.gemm(a, w, a2=a2, residual=full, **kw)
+    assert torch.equal(got, want) and bool(torch.isfinite(got.float()).all())
+    if kw:
+        assert torch.equal(st_got, kw['ln_stats_out'])
+    ref = a.float().cpu() @ w.w.float().cpu()[:, :K].T + (a2.float().cpu() @ w.w.float().cpu()[:, K:].T if K2 else 0) + w.bias.cpu() + full.float().cpu()
+    close(got[:, :N].float().cpu(), ref, rtol=4e-3, atol=2e-2)
+
+
+def test_gemm_residual_rows_is_refused_where_it_cannot_run(dev):
+    from flexdiffuse_amd import hip, ops
+    a = torch.randn((1024, 320)).half().to(dev)
+    w = ops.prep_linear(torch.randn((320, 320)) * 0.05, None, dev)
+    with pytest.raises(AssertionError):
+        ops.gemm(a, w, residual=torch.zeros((384, 320), dtype=torch.float16, device=dev))      # 1024 % 384 != 0
+    with pytest.raises((hip.FDError, ValueError)):
+        ops.gemm(a, w, residual=torch.zeros((128, 320), dtype=torch.float16, device=dev))      # a 256-row tile would straddle the wrap
+    assert ops.residual_wrap_supported(32768, 2) and ops.residual_wrap_supported(36864, 2) and not ops.residual_wrap_supported(1000, 2)
+    assert not ops.residual_wrap_supported(768, 3)          # 2304 output rows could take the 288-row tile, 768 is not a multiple of it
 
 
 @pytest.mark.parametrize('B,HW,C', [(16, 4096, 320), (8, 4096, 320), (16, 1024, 640), (16, 256, 1280), (16, 64, 1280), (2, 576, 640)])

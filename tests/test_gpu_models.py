@@ -982,6 +982,72 @@ def test_unet_producer_side_groupnorm_equals_separate_launches(sd15, dev):
     assert torch.equal(a, b) and bool(torch.isfinite(a).all())
 
 
+def test_unet_cfg_fanout_residuals_read_modulo_equal_the_replicas(sd15, dev):
+    '''Full-size SD1.5 forward with the CFG fan-out (8 latents, 2 contexts): behind the shared prefix the hidden states and the block input are
+    residuals only, read modulo the prefix's rows (fd_gemm_desc.residual_rows) instead of from replicas written by fd_repeat_rows_f16.
+    Same bits as with the replicas (ops.RES_WRAP = False), two launches fewer.'''
+    from flexdiffuse_amd import hip, ops
+    sds, pipe, clip, tok, _ = sd15
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn((8, 4, 64, 64), generator=g).to(dev)
+    ctx = torch.randn((16, 77, 768), generator=g).half().to(dev)
+
+    def run():
+        plan = hip.Plan()
+        with plan.record():
+            out = pipe.unet.forward_nhwc(x, 321, ctx, rep=2).clone()
+        return out, len(plan)
+    assert ops.RES_WRAP
+    pipe.unet.forward_nhwc(x, 321, ctx, rep=2)          # (the context's K / V^T projections happen once, outside the recorded forwards)
+    a, na = run()
+    ops.RES_WRAP = False
+    try:
+        b, nb = run()
+    finally:
+        ops.RES_WRAP = True
+    print(f'recorded launches per forward: {na} with the residuals read modulo the prefix rows, {nb} with replicas')
+    assert nb - na == 2, (na, nb)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
+def test_unet_conv_in_in_one_launch_against_the_gemm_path(sd15, dev):
+    '''Full-size SD1.5 forward with the CFG fan-out: conv_in as ONE launch from the fp32 NCHW latents (fd_conv3x3_narrow_f16, replicas of the
+    first skip tensor included) against layout change + explicit im2col + GEMM + fan-out copy (ops.CONV_IN_DIRECT = False): three launches
+    fewer; the same fp16 products summed in another order, so the noise prediction agrees to the forward's fp16 noise, not bit for bit.'''
+    from flexdiffuse_amd import hip, ops
+    sds, pipe, clip, tok, _ = sd15
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn((8, 4, 64, 64), generator=g).to(dev)
+    ctx = torch.randn((16, 77, 768), generator=g).half().to(dev)
+    pipe.unet.forward_nhwc(x, 321, ctx, rep=2)
+
+    def run():
+        plan = hip.Plan()
+        with plan.record():
+            out = pipe.unet.forward_nhwc(x, 321, ctx, rep=2).clone()
+        return out, len(plan)
+    assert ops.CONV_IN_DIRECT and pipe.unet.conv_in_nw is not None
+    a, na = run()
+    a2, _ = run()
+    ops.CONV_IN_DIRECT = False
+    try:
+        b, nb = run()
+    finally:
+        ops.CONV_IN_DIRECT = True
+    rel = float((a - b).abs().max() / b.abs().max())
+    print(f'recorded launches per forward: {na} with conv_in in one launch, {nb} through the GEMM path; max |d eps| / max |eps| = {rel:.2e}')
+    assert nb - na == 3, (na, nb)
+    assert torch.equal(a, a2) and bool(torch.isfinite(a).all()) and rel < 5e-3, rel
+    # the single-sample, no-fan-out call takes the same kernel
+    c = pipe.unet.forward_nhwc(x[:1], 321, ctx[:1], rep=1)
+    ops.CONV_IN_DIRECT = False
+    try:
+        d = pipe.unet.forward_nhwc(x[:1], 321, ctx[:1], rep=1)
+    finally:
+        ops.CONV_IN_DIRECT = True
+    assert float((c - d).abs().max() / d.abs().max()) < 5e-3
+
+
 def test_clip_towers_through_their_launch_plans(sd15, dev):
     '''The transformer stacks of the full-size CLIP ViT-L/14 towers run from launch plans (clip._PlannedEncoder: one library call per
     tower instead of ~360 trips through the Python front).  First call (records), replays, and the eager front (FD_CLIP_PLAN=0) give
