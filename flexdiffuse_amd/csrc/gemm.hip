@@ -823,7 +823,7 @@ __device__ __forceinline__ void splitk_finish_body(const GemmArgs& g) {
         half4 rr = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
         if (g.bias) bb = *reinterpret_cast<const float4*>(g.bias + nb0);
         if (g.bias2) b2 = *reinterpret_cast<const float4*>(g.bias2 + (size_t)(m / g.rows_per_batch) * g.ldb2 + nb0);
-        if (g.res) rr = *reinterpret_cast<const half4*>(g.res + (size_t)m * g.ldr + nb0);
+        if (g.res) rr = *reinterpret_cast<const half4*>(g.res + (size_t)(g.res_rows ? m % g.res_rows : m) * g.ldr + nb0);
         float4 a = p[0];
         if constexpr (S > 0) {
 #pragma unroll
@@ -1650,10 +1650,11 @@ static int gemm_impl(const fd_gemm_desc* d, void* stream, int* choice) {
                      best_tile, best_split, g.M, g.N);
     }
     if (g.res_rows) {
-        // the lean epilogues wrap the residual row once per wave row block: a tile must not straddle the wrap; the finish pass of a split launch does not wrap
+        // the lean epilogues wrap the residual row once per wave row block: a tile must not straddle the wrap (the finish pass of a launch split
+        // over K adds the residual and wraps per row)
         const int bm = best_tile == 23 ? 288 : 256;
-        FD_CHECK_ARG(best_split == 1 && g.res_rows % bm == 0, FD_ESHAPE,
-                     "fd_gemm_f16: residual_rows=%d with tile %d / split_k %d (needs split_k 1 and a multiple of %d rows)", g.res_rows, best_tile, best_split, bm);
+        FD_CHECK_ARG(best_split > 1 || g.res_rows % bm == 0, FD_ESHAPE,
+                     "fd_gemm_f16: residual_rows=%d with tile %d (needs a multiple of %d rows)", g.res_rows, best_tile, bm);
     }
     if (best_split > 1)
         FD_CHECK_ARG(!geglu && batch == 1 && g.N % 4 == 0 && g.ws &&

@@ -273,7 +273,7 @@ typedef struct fd_gemm_desc {
     float ln_fold_eps; /* 0 = 1e-5 */
     /* (ABI 12) residual_rows > 0: output row m adds residual row m %% residual_rows -- the residual of a GEMM whose rows are `rep` replicas of
      * a shared prefix (the classifier-free-guidance fan-out inside `unet(...)`, reference pipeline/guide.py:56-58: both halves of the batch read
-     * the same hidden states until the first cross-attention) without materialising the replicas.  Linear GEMM, batch 1, split_k 1,
+     * the same hidden states until the first cross-attention) without materialising the replicas.  Linear GEMM, batch 1,
      * M %% residual_rows == 0 and residual_rows a multiple of the tile's rows (256 covers every tile but the 288-row one).  0 = row m. */
     int32_t residual_rows;
 } fd_gemm_desc;
