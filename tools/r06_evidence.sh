@@ -5,6 +5,7 @@ mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-$PWD}
 export PYTHONPATH=$R
 bash tools/pmc_traffic_r06.sh gpurun_out/pmc_traffic_r06 $R/gpurun_out/r06_pmc_traffic.json > gpurun_out/r06_pmc_traffic.log 2>&1
+cp $R/gpurun_out/r06_pmc_traffic.json $R/profiles/r06_pmc_traffic.json    # the bench lines below quote this record (bound to the GEMM sources by sources_sha)
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r06_prof -o bench --output-format csv -- python3 $R/bench.py --no-parity --no-cpu-baseline --steps 4 --warmup 1 > $R/gpurun_out/r06_bench_under_rocprof.json 2> $R/gpurun_out/r06_bench_under_rocprof.err
 cd $R
