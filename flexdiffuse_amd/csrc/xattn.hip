@@ -42,6 +42,8 @@ struct XattnArgs {
     half_t* O;              // [nrep * M][ldo]
     int M, lda, ldw, ldo;
     int rows_per_sample, samples_per_rep, n_keys;
+    int ln_parts;           // > 0: ln_stats holds the producer's k partial slabs [k][M][2] (sum, sum of squares): every tile finalises its own rows
+    float ln_inv_n, ln_eps;
 };
 
 constexpr int XA_KB = 5;   // 16-key blocks (80 >= 77 keys)
@@ -200,8 +202,26 @@ __global__ __launch_bounds__(1024) void k_xattn(XattnArgs g, unsigned a_bytes, u
         // the tile's LayerNorm row statistics ride along too: a global load in the epilogue would be waited
         // for with vmcnt(0), i.e. together with the V^T image DMA issued just before it
         const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(g.ln_stats + 2 * (size_t)m0), 0, BM * 8u, 0x00020000);
-        if (wave < BM * 2 / 64)
+        if (g.ln_parts) {
+            // the producer's partial sums (fd_xattn_desc.ln_stats_parts): fd_ln_finalize_stats_f32's arithmetic, bit for bit (fixed slab order), without
+            // the launch; the LDS writes are ordered before their readers by the barriers of the projection's K loop
+            const int t = wave * 64 + lane;
+            if (t < BM) {
+                const float* p = g.ln_stats + 2 * (size_t)(m0 + t);
+                float s1 = 0.f, s2 = 0.f;
+                for (int k = 0; k < g.ln_parts; ++k) {
+                    const floatx2 v = *reinterpret_cast<const floatx2*>(p + 2 * (size_t)k * g.M);
+                    s1 += v[0];
+                    s2 += v[1];
+                }
+                const float mean = s1 * g.ln_inv_n;
+                const float var = fmaxf(fmaf(-mean, mean, s2 * g.ln_inv_n), 0.f);
+                const float rstd = rsqrtf(var + g.ln_eps);
+                *reinterpret_cast<floatx2*>(stats_s + 2 * t) = floatx2{rstd, -mean * rstd};
+            }
+        } else if (wave < BM * 2 / 64) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lds_ptr)(stats_s + wave * 64), 4, (unsigned)(wave * 64 + lane) * 4u, 0, 0, 0);
+        }
     }
     {
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(g.bias + n0), 0, BN * 4u, 0x00020000);
@@ -475,6 +495,9 @@ extern "C" int fd_xattn_q_f16(const fd_xattn_desc* d, void* stream) {
     g.M = d->M; g.lda = d->ldx; g.ldw = d->ldw; g.ldo = d->ldo;
     g.rows_per_sample = d->rows_per_sample;
     g.samples_per_rep = d->M / d->rows_per_sample; g.n_keys = d->n_keys;
+    FD_CHECK_ARG(d->ln_stats_parts == 0 || d->ln_stats_parts == 2 || d->ln_stats_parts == 4 || d->ln_stats_parts == 8, FD_ESHAPE,
+                 "fd_xattn_q_f16: ln_stats_parts=%d (0, 2, 4 or 8)", d->ln_stats_parts);
+    g.ln_parts = d->ln_stats_parts; g.ln_inv_n = 1.0f / (float)C; g.ln_eps = d->ln_fold_eps > 0.f ? d->ln_fold_eps : 1e-5f;
     hipStream_t st = (hipStream_t)stream;
     // priced like the two launches it replaces: the q projection (2 M C C, once) and the attention proper
     // (4 heads Nq Nk d per replica)

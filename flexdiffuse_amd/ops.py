@@ -649,7 +649,7 @@ class fd_xattn_desc(ctypes.Structure):
                 ('ln_stats', c_void_p), ('k_image', c_void_p), ('v_image', c_void_p), ('out', c_void_p),
                 ('M', c_int32), ('ldx', c_int32), ('ldw', c_int32), ('ldo', c_int32),
                 ('rows_per_sample', c_int32), ('n_rep', c_int32), ('n_keys', c_int32), ('heads', c_int32),
-                ('head_dim', c_int32)]
+                ('head_dim', c_int32), ('ln_stats_parts', c_int32), ('ln_fold_eps', c_float)]
 
 
 def xattn_row_tile(head_dim: int) -> int:
@@ -684,7 +684,9 @@ def xattn_q(x: torch.Tensor, w: LinW, ln_stats: torch.Tensor, images: Tuple[torc
     queries: x [M][C] un-normalised fp16 -> [n_rep*M][C] fp16.  `w` from prep_linear_ln with the softmax
     scale * log2(e) folded in.'''
     M, C = x.shape
-    assert w.colsum is not None and w.bias is not None and ln_stats.shape == (M, 2) and x.stride(1) == 1
+    assert w.colsum is not None and w.bias is not None and x.stride(1) == 1 and ln_stats.dtype == torch.float32 and ln_stats.is_contiguous()
+    # [M][2]: finished pairs; [k][M][2]: the producer's partial slabs, finalised by the kernel's tiles (fd_xattn_desc.ln_stats_parts)
+    assert ln_stats.shape == (M, 2) or (ln_stats.dim() == 3 and ln_stats.shape[0] in (2, 4, 8) and ln_stats.shape[1:] == (M, 2)), tuple(ln_stats.shape)
     assert images[0].shape[0] == n_rep * (M // rows_per_sample)
     if out is None:
         out = _empty((n_rep * M, C), torch.float16, x)
@@ -693,6 +695,8 @@ def xattn_q(x: torch.Tensor, w: LinW, ln_stats: torch.Tensor, images: Tuple[torc
     d.ln_stats, d.k_image, d.v_image, d.out = ln_stats.data_ptr(), images[0].data_ptr(), images[1].data_ptr(), out.data_ptr()
     d.M, d.ldx, d.ldw, d.ldo = M, x.stride(0), w.w.stride(0), out.stride(0)
     d.rows_per_sample, d.n_rep, d.n_keys, d.heads, d.head_dim = rows_per_sample, n_rep, n_keys, heads, head_dim
+    if ln_stats.dim() == 3:
+        d.ln_stats_parts, d.ln_fold_eps = ln_stats.shape[0], 1e-5
     hip.call('fd_xattn_q_f16', ctypes.byref(d), hip.stream())
     return out
 

@@ -372,7 +372,7 @@ class UNet2DConditionModel():
         if a.ctx_img is not None and HW % ops.xattn_row_tile(d) == 0:
             # q projection + cross-attention in one launch (the query matrix never goes to HBM); `rep`
             # context replicas share the queries
-            o = ops.xattn_q(h, a.q2, fin(st, h), a.ctx_img, HW, L, a.heads, d, n_rep=rep)
+            o = ops.xattn_q(h, a.q2, fin(st, h, parts_ok=True), a.ctx_img, HW, L, a.heads, d, n_rep=rep)
         else:
             if a.ln_fold:
                 q2 = ops.gemm(h, a.q2, ln_stats=fin(st, h, parts_ok=True))

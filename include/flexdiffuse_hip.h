@@ -343,6 +343,11 @@ typedef struct fd_xattn_desc {
     int32_t rows_per_sample; /* query rows per sample; a multiple of 256 */
     int32_t n_rep;           /* context replicas sharing the same queries (CFG fan-out of a shared prefix); >= 1 */
     int32_t n_keys, heads, head_dim;
+    /* (ABI 12) ln_stats_parts = k in {2, 4, 8}: ln_stats holds the k partial slabs [k][M][2] (sum, sum of squares per 160-column tile) that the
+     * producer GEMM wrote through fd_gemm_desc.ln_stats_out; every tile finalises its own rows (fd_ln_finalize_stats_f32's arithmetic, bit for
+     * bit, over heads * head_dim columns with ln_fold_eps) -- as fd_gemm_desc.ln_stats_parts does for the GEMM consumers.  0 = finished pairs. */
+    int32_t ln_stats_parts;
+    float ln_fold_eps;       /* 0 = 1e-5 */
 } fd_xattn_desc;
 int fd_xattn_q_f16(const fd_xattn_desc* desc, void* stream);
 

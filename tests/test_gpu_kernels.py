@@ -653,6 +653,16 @@ def test_fused_q_projection_cross_attention(dev, B, HW, rep, L, d):
     if rep == 2:   # the replicas really saw different contexts
         assert float((got[:M] - got[M:]).abs().max()) > 0.05
     assert not ops.xattn_supported(8, 64, L, HW) and not ops.xattn_supported(heads, d, 64, HW)
+    # the producer's PARTIAL sums instead of finished statistics (fd_xattn_desc.ln_stats_parts): every tile finalises its own rows -- the bits of
+    # fd_ln_finalize_stats_f32 + the launch above
+    for kparts in (2, 4):
+        xs = xd.float().view(M, kparts, C // kparts)
+        parts = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).permute(1, 0, 2).contiguous()      # [k][M][2]
+        fin = ops.ln_finalize_stats(parts, C)
+        a = ops.xattn_q(xd, lw, fin, img, HW, L, heads, d, n_rep=rep)
+        b = ops.xattn_q(xd, lw, parts, img, HW, L, heads, d, n_rep=rep)
+        assert torch.equal(a, b) and bool(torch.isfinite(b.float()).all())
+        assert float((b.float().cpu() - got).abs().max()) <= 2e-2 * float(got.abs().max())
     assert not ops.xattn_supported(heads, d, L, 64) and not ops.xattn_supported(5, 64, L, HW)
 
 
